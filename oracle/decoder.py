@@ -1,0 +1,222 @@
+"""Text decoder + greedy loop: CPU restatement of `QuantizedTextModel` / `FloatTextModel`
+and `Qwen3ASRModel.generateText`.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows:
+  * Sources/Qwen3ASR/QuantizedTextDecoder.swift:56-105  attention: q/k/v proj, per-head q/k
+    RMSNorm, split-half RoPE (offset = cache length), cache append, GQA SDPA, o_proj
+  * :132-137 SwiGLU MLP; :156-174 pre-norm residual layer; :202-251 model forward,
+    causal mask where(col > row + cacheLen, -1e9, 0) for T_q > 1, no mask for T_q == 1
+  * Sources/Qwen3ASR/FloatTextDecoder.swift:35-226 (bf16 twin, identical structure, Linear)
+  * Sources/MLXCommon/PreQuantizedEmbedding.swift:35-49 (embedding lookup; tied LM head)
+  * Sources/Qwen3ASR/Qwen3ASR.swift:236-256 (splice audio embeddings, cast to embed dtype,
+    last-position logits), :317-390 greedy loop (append then break on EOS), :449-520 sampler
+Third-party arithmetic not in the reference tree (mlx-swift >= 0.30.0, unpinned):
+  * RMSNorm: y = w * T(x * rsqrt(mean(x^2) + eps)), internal float32            (mlx fast::rms_norm)
+  * RoPE(traditional=false): theta_i = base^(-i/(d/2)); out = [x1*cos - x2*sin, x1*sin + x2*cos]
+  * outputs of every op are rounded to the tensor dtype (bf16 in the decoder)
+  * argMax returns the lowest index among equal maxima; logits are bf16 (x dtype)
+"""
+import math
+import numpy as np
+import torch
+from .config import TextDecoderConfig, TokenIds, TOKENS
+from . import precision as P
+
+
+class Weights:
+    """State dict wrapper with cached float32 views (weights are stored bf16/f32 tensors)."""
+
+    def __init__(self, sd):
+        self.sd = sd
+        self._f32 = {}
+
+    def __call__(self, key):
+        t = self._f32.get(key)
+        if t is None:
+            t = self.sd[key].to(torch.float32)
+            self._f32[key] = t
+        return t
+
+
+def rms_norm(x, w, eps, pol: P.Policy):
+    inv = torch.rsqrt((x * x).mean(dim=-1, keepdim=True) + eps)
+    return pol.dec(w * pol.dec(x * inv))
+
+
+def rope(x, positions, theta):
+    """x [T, heads, hd]; split-half rotation (MLXNN.RoPE traditional=false)."""
+    hd = x.shape[-1]
+    half = hd // 2
+    inv = torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(theta) / half))
+    ang = positions.to(torch.float32)[:, None] * inv[None, :]
+    cos, sin = torch.cos(ang)[:, None, :], torch.sin(ang)[:, None, :]
+    x1, x2 = x[..., :half], x[..., half:]
+    return torch.cat([x1 * cos - x2 * sin, x1 * sin + x2 * cos], dim=-1)
+
+
+class DecoderState:
+    """KV cache: per layer (K [kv_heads, ctx, hd], V [kv_heads, ctx, hd]) grown by concat."""
+
+    def __init__(self, layers):
+        self.k = [None] * layers
+        self.v = [None] * layers
+
+    @property
+    def length(self):
+        return 0 if self.k[0] is None else self.k[0].shape[1]
+
+
+def forward(embeds, W: Weights, cfg: TextDecoderConfig, state: DecoderState, pol: P.Policy,
+            p_bf16=None):
+    """embeds [T, hidden] (already in decoder dtype) -> final-normed hidden [T, hidden]."""
+    T = embeds.shape[0]
+    off = state.length
+    pos = torch.arange(off, off + T)
+    if p_bf16 is None:
+        p_bf16 = pol.dec_bf16 and T > 1       # MFMA prefill rounds P; the T_q=1 path keeps f32
+    scale = 1.0 / math.sqrt(cfg.head_dim)
+    rep = cfg.heads // cfg.kv_heads
+    x = embeds
+    for i in range(cfg.layers):
+        p = f"model.layers.{i}"
+        h = rms_norm(x, W(p + ".input_layernorm.weight"), cfg.rms_eps, pol)
+        q = pol.dec(h @ W(p + ".self_attn.q_proj.weight").T).reshape(T, cfg.heads, cfg.head_dim)
+        k = pol.dec(h @ W(p + ".self_attn.k_proj.weight").T).reshape(T, cfg.kv_heads, cfg.head_dim)
+        v = pol.dec(h @ W(p + ".self_attn.v_proj.weight").T).reshape(T, cfg.kv_heads, cfg.head_dim)
+        q = rms_norm(q, W(p + ".self_attn.q_norm.weight"), cfg.rms_eps, pol)
+        k = rms_norm(k, W(p + ".self_attn.k_norm.weight"), cfg.rms_eps, pol)
+        q = pol.dec(rope(q, pos, cfg.rope_theta))
+        k = pol.dec(rope(k, pos, cfg.rope_theta))
+        kT, vT = k.transpose(0, 1), v.transpose(0, 1)              # [kv, T, hd]
+        if state.k[i] is not None:
+            kT = torch.cat([state.k[i], kT], dim=1)
+            vT = torch.cat([state.v[i], vT], dim=1)
+        state.k[i], state.v[i] = kT, vT
+        ctx = kT.shape[1]
+        qh = q.transpose(0, 1)                                     # [heads, T, hd]
+        kh = kT.repeat_interleave(rep, dim=0)
+        vh = vT.repeat_interleave(rep, dim=0)
+        sc = (qh @ kh.transpose(1, 2)) * scale                     # [heads, T, ctx]
+        if T > 1:
+            col = torch.arange(ctx)[None, :]
+            row = (torch.arange(T) + off)[:, None]
+            sc = sc + torch.where(col > row, torch.tensor(-1e9), torch.tensor(0.0))[None]
+        pr = torch.softmax(sc, dim=-1)
+        if p_bf16:
+            pr = P.bf16_round(pr)
+        a = pol.dec(pr @ vh).transpose(0, 1).reshape(T, cfg.heads * cfg.head_dim)
+        x = pol.dec(x + pol.dec(a @ W(p + ".self_attn.o_proj.weight").T))
+        h = rms_norm(x, W(p + ".post_attention_layernorm.weight"), cfg.rms_eps, pol)
+        g = pol.dec(h @ W(p + ".mlp.gate_proj.weight").T)
+        u = pol.dec(h @ W(p + ".mlp.up_proj.weight").T)
+        act = pol.dec(pol.dec(g * torch.sigmoid(g)) * u)
+        x = pol.dec(x + pol.dec(act @ W(p + ".mlp.down_proj.weight").T))
+    return rms_norm(x, W("model.norm.weight"), cfg.rms_eps, pol)
+
+
+def embed(ids, W: Weights):
+    return W("model.embed_tokens.weight")[torch.as_tensor(ids, dtype=torch.long)]
+
+
+def lm_head(h_last, W: Weights, pol: P.Policy):
+    """Tied head on one position: [hidden] -> [vocab] logits in the decoder dtype."""
+    return pol.dec(W("model.embed_tokens.weight") @ h_last)
+
+
+def argmax_lowest(logits):
+    """MLX argMax: first index of the maximum."""
+    return int(torch.argmax(logits).item()) if logits.numel() else 0
+
+
+def build_prompt(n_audio, tok: TokenIds = TOKENS, context_ids=None, language_ids=None):
+    """Qwen3ASR.swift:199-233 -> (ids, audio_start_index)."""
+    ids = [tok.im_start, tok.system, tok.newline]
+    if context_ids:
+        ids += list(context_ids)
+    ids += [tok.im_end, tok.newline]
+    ids += [tok.im_start, tok.user, tok.newline, tok.audio_start]
+    a0 = len(ids)
+    ids += [tok.audio_pad] * n_audio
+    ids += [tok.audio_end, tok.im_end, tok.newline]
+    ids += [tok.im_start, tok.assistant, tok.newline]
+    if language_ids:
+        ids += list(language_ids)
+    ids.append(tok.asr_text)
+    return ids, a0
+
+
+def prefill(audio_embeds, W: Weights, cfg: TextDecoderConfig, pol: P.Policy,
+            tok: TokenIds = TOKENS, context_ids=None, language_ids=None):
+    """Qwen3ASR.swift:236-256 -> (logits [vocab], state, prompt ids)."""
+    n_audio = audio_embeds.shape[0]
+    ids, a0 = build_prompt(n_audio, tok, context_ids, language_ids)
+    x = embed(ids, W).clone()
+    x[a0:a0 + n_audio] = pol.dec(torch.as_tensor(audio_embeds, dtype=torch.float32))
+    state = DecoderState(cfg.layers)
+    h = forward(x, W, cfg, state, pol)
+    return lm_head(h[-1], W, pol), state, ids
+
+
+def decode_step(token, W: Weights, cfg: TextDecoderConfig, state: DecoderState, pol: P.Policy):
+    h = forward(embed([token], W), W, cfg, state, pol)
+    return lm_head(h[-1], W, pol)
+
+
+def greedy(audio_embeds, W: Weights, cfg: TextDecoderConfig, pol: P.Policy = P.REFERENCE,
+           tok: TokenIds = TOKENS, max_tokens=448, context_ids=None, language_ids=None,
+           ignore_eos=False, return_logits=False):
+    """`generateGreedyAsyncEval` Qwen3ASR.swift:317-390: EOS is appended, then the loop stops.
+
+    `ignore_eos` forces exactly `max_tokens` tokens (bench workload: fixed decode length).
+    """
+    out, all_logits = [], []
+    if max_tokens <= 0:
+        return (out, all_logits) if return_logits else out
+    logits, state, _ = prefill(audio_embeds, W, cfg, pol, tok, context_ids, language_ids)
+    nxt = argmax_lowest(logits)
+    for step in range(max_tokens):
+        out.append(nxt)
+        if return_logits:
+            all_logits.append(logits)
+        if nxt == tok.eos and not ignore_eos:
+            break
+        if step + 1 >= max_tokens:
+            break
+        logits = decode_step(nxt, W, cfg, state, pol)
+        nxt = argmax_lowest(logits)
+    return (out, all_logits) if return_logits else out
+
+
+def pick_next_token(logits, generated, repetition_penalty=1.0, no_repeat_ngram=0, temperature=0.0,
+                    rng=None):
+    """`pickNextToken` Qwen3ASR.swift:449-520 (CPU sampler of the slow path)."""
+    scores = np.asarray(logits, dtype=np.float32).reshape(-1).copy()
+    V = scores.shape[0]
+    if repetition_penalty == 1.0 and no_repeat_ngram == 0 and temperature == 0:
+        return int(np.argmax(scores))
+    if repetition_penalty > 1.0 and len(generated):
+        for t in set(int(g) for g in generated):
+            if 0 <= t < V:
+                v = scores[t]
+                scores[t] = v / np.float32(repetition_penalty) if v > 0 else v * np.float32(repetition_penalty)
+    n = no_repeat_ngram
+    if n > 0 and len(generated) >= n - 1:
+        g = [int(x) for x in generated]
+        last = g[len(g) - (n - 1):] if n > 1 else []
+        if len(g) >= n:
+            for i in range(0, len(g) - n + 1):
+                if g[i:i + n - 1] == last:
+                    f = g[i + n - 1]
+                    if 0 <= f < V:
+                        scores[f] = -np.inf
+    if temperature > 0:
+        rng = rng or np.random.default_rng()
+        u = rng.uniform(1e-6, 1.0, size=V).astype(np.float32)
+        scores = scores / np.float32(temperature) - np.log(-np.log(u))
+    best, best_s = 0, -np.inf
+    for i in range(V):                      # strict '>' : first maximum wins (:515-518)
+        if scores[i] > best_s:
+            best_s, best = scores[i], i
+    return int(best)

@@ -1,0 +1,88 @@
+"""Synthetic weights and waveforms (there is no checkpoint or dataset offline).
+
+Recipes are the ones SURVEY.md section 8(d) fixes, so bench numbers and parity tests are
+reproducible:
+  * weights: `torch.manual_seed(seed)`; N(0, 0.02) for Linear/Conv/Embedding, norm weight 1,
+    bias 0 (HF `initializer_range`), cast to bf16.  `init="stress"` instead draws
+    N(0, 1/fan_in) weights, non-zero biases and non-unit norm gains so that attention is
+    peaked and every bias/gain path is exercised by the parity tests.
+  * waveform k: 0.4 sin(2 pi f1 t) + 0.2 sin(2 pi f2 t) + 0.05 N(0,1), f1 = 220 + 37k,
+    f2 = 1200 + 91k, rng(20260418 + k), quantised to PCM16 and back.
+Tensor names/layouts are the reference checkpoint's (Sources/Qwen3ASR/WeightLoading.swift:
+235-323): conv weights [out, kH, kW, in]; Linear [out, in]; float decoder (FloatTextDecoder).
+"""
+import math
+import numpy as np
+import torch
+
+
+def synth_waveform(k: int, seconds: float, sample_rate: int = 16000) -> np.ndarray:
+    n = int(round(seconds * sample_rate))
+    rng = np.random.default_rng(20260418 + k)
+    t = np.arange(n, dtype=np.float64) / sample_rate
+    f1, f2 = 220.0 + 37.0 * k, 1200.0 + 91.0 * k
+    x = 0.4 * np.sin(2 * np.pi * f1 * t) + 0.2 * np.sin(2 * np.pi * f2 * t) + 0.05 * rng.standard_normal(n)
+    pcm16 = np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)
+    return (pcm16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+def synth_state_dict(audio_cfg, text_cfg, seed: int = 0, init: str = "hf", dtype=torch.bfloat16):
+    """audio_cfg / text_cfg: any objects with the fields of qasr.config presets."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def w(name, *shape, fan_in=None):
+        std = 0.02 if init == "hf" else 1.0 / math.sqrt(fan_in if fan_in else shape[-1])
+        sd[name] = (torch.randn(*shape, generator=g) * std).to(dtype)
+
+    def b(name, n):
+        sd[name] = (torch.zeros(n) if init == "hf" else torch.randn(n, generator=g) * 0.05).to(dtype)
+
+    def gain(name, n):
+        sd[name] = (torch.ones(n) if init == "hf" else 1.0 + 0.1 * torch.randn(n, generator=g)).to(dtype)
+
+    a = audio_cfg
+    C = a.conv_channels
+    w("audio_tower.conv2d1.weight", C, 3, 3, 1, fan_in=9)
+    b("audio_tower.conv2d1.bias", C)
+    for n in ("conv2d2", "conv2d3"):
+        w(f"audio_tower.{n}.weight", C, 3, 3, C, fan_in=9 * C)
+        b(f"audio_tower.{n}.bias", C)
+    w("audio_tower.conv_out.weight", a.d_model, a.conv_out_in)
+    for i in range(a.layers):
+        p = f"audio_tower.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            w(f"{p}.self_attn.{n}.weight", a.d_model, a.d_model)
+            b(f"{p}.self_attn.{n}.bias", a.d_model)
+        for n in ("self_attn_layer_norm", "final_layer_norm"):
+            gain(f"{p}.{n}.weight", a.d_model)
+            b(f"{p}.{n}.bias", a.d_model)
+        w(f"{p}.fc1.weight", a.ffn_dim, a.d_model)
+        b(f"{p}.fc1.bias", a.ffn_dim)
+        w(f"{p}.fc2.weight", a.d_model, a.ffn_dim)
+        b(f"{p}.fc2.bias", a.d_model)
+    gain("audio_tower.ln_post.weight", a.d_model)
+    b("audio_tower.ln_post.bias", a.d_model)
+    w("audio_tower.proj1.weight", a.d_model, a.d_model)
+    b("audio_tower.proj1.bias", a.d_model)
+    w("audio_tower.proj2.weight", a.output_dim, a.d_model)
+    b("audio_tower.proj2.bias", a.output_dim)
+
+    t = text_cfg
+    sd["model.embed_tokens.weight"] = (torch.randn(t.vocab, t.hidden, generator=g) *
+                                       (0.02 if init == "hf" else 0.05)).to(dtype)
+    for i in range(t.layers):
+        p = f"model.layers.{i}"
+        w(f"{p}.self_attn.q_proj.weight", t.heads * t.head_dim, t.hidden)
+        w(f"{p}.self_attn.k_proj.weight", t.kv_heads * t.head_dim, t.hidden)
+        w(f"{p}.self_attn.v_proj.weight", t.kv_heads * t.head_dim, t.hidden)
+        w(f"{p}.self_attn.o_proj.weight", t.hidden, t.heads * t.head_dim)
+        gain(f"{p}.self_attn.q_norm.weight", t.head_dim)
+        gain(f"{p}.self_attn.k_norm.weight", t.head_dim)
+        gain(f"{p}.input_layernorm.weight", t.hidden)
+        gain(f"{p}.post_attention_layernorm.weight", t.hidden)
+        w(f"{p}.mlp.gate_proj.weight", t.inter, t.hidden)
+        w(f"{p}.mlp.up_proj.weight", t.inter, t.hidden)
+        w(f"{p}.mlp.down_proj.weight", t.hidden, t.inter)
+    gain("model.norm.weight", t.hidden)
+    return sd
