@@ -1,0 +1,173 @@
+/* qasr.h -- C ABI of libqasr.so: MI355X-native (gfx950) Qwen3-ASR transcribe() hot path.
+ *
+ * Drop-in boundary for ivan-digital/qwen3-asr-swift.  Every entry point names the reference
+ * interface it replaces (file:line under the reference tree).  Plain pointers and sizes only.
+ *
+ *   Qwen3ASRModel.fromPretrained(modelId:cacheDir:...)   Sources/Qwen3ASR/Qwen3ASR.swift:608-668
+ *        -> qasr_default_config + qasr_create (+ qasr_set_tensor / qasr_finalize for in-memory weights)
+ *   Qwen3ASRModel.transcribe(audio:sampleRate:language:maxTokens:context:)   Qwen3ASR.swift:131-164
+ *   SpeechRecognitionModel.transcribe / inputSampleRate   Sources/AudioCommon/Protocols.swift:151-165,
+ *                                                         Sources/Qwen3ASR/Qwen3ASR+Protocols.swift:5-11
+ *        -> qasr_transcribe, qasr_input_sample_rate
+ *   sc_stt_vtable_t.transcribe callback                   Sources/SpeechCore/VoicePipeline.swift:374-410
+ *        -> qasr_stt_vtable (same field order / ownership rules)
+ *   ModelMemoryManageable isLoaded/unload/memoryFootprint Sources/Qwen3ASR/Qwen3ASR+Memory.swift:3-18
+ *        -> qasr_is_loaded, qasr_unload, qasr_memory_footprint
+ *   TranscribeBatchCommand (sequential loop in the reference; batched here)
+ *                                                         Sources/AudioCLILib/TranscribeBatchCommand.swift:69-133
+ *        -> qasr_batch_begin / qasr_batch_run / qasr_batch_tokens, qasr_transcribe_batch
+ *   Stage entry points (no reference counterpart; they expose R1-R8 of SURVEY.md section 8a so
+ *   each kernel can be diffed against the oracle in isolation): qasr_mel, qasr_encode,
+ *   qasr_prefill_logits, qasr_decode_forced.
+ *
+ * Threading: like the reference ("not thread-safe", Qwen3ASR.swift:67) one engine = one HIP
+ * device + one stream, not re-entrant; use one engine per GPU.
+ * Errors: integer status (0 = ok) + qasr_last_error(engine).  transcribe() in the reference never
+ * throws (Qwen3ASR.swift:151-154); shims convert a non-zero status to "[qasr error: ...]".
+ */
+#ifndef QASR_H
+#define QASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QASR_OK 0
+#define QASR_ERR_INVALID 1      /* bad argument / shape */
+#define QASR_ERR_HIP 2          /* HIP runtime failure (message in qasr_last_error) */
+#define QASR_ERR_NOT_LOADED 3   /* weights missing / engine unloaded */
+#define QASR_ERR_IO 4           /* checkpoint directory / file problem */
+#define QASR_ERR_CAPACITY 5     /* batch or clip exceeds the engine's configured capacity */
+#define QASR_ERR_EMPTY_AUDIO 6  /* zero-length clip (the reference traps on it) */
+
+#define QASR_DTYPE_F32 0
+#define QASR_DTYPE_BF16 1
+#define QASR_DTYPE_F16 2
+#define QASR_DTYPE_U32 3
+
+typedef struct qasr_engine qasr_engine;
+
+/* Compile-time presets of the reference (Sources/Qwen3ASR/AudioEncoder.swift:28-88,
+ * Configuration.swift:47-108) plus engine capacity knobs. */
+typedef struct qasr_config {
+    /* audio encoder */
+    int32_t enc_d_model, enc_heads, enc_ffn, enc_layers, n_mels, enc_out_dim, conv_channels;
+    int32_t n_window, n_window_infer;
+    float ln_eps;
+    /* text decoder */
+    int32_t vocab, hidden, dec_layers, heads, kv_heads, head_dim, inter;
+    float rms_eps, rope_theta;
+    int32_t group_size, bits;          /* MLX affine quantisation of the checkpoint (4 / 8); 16 = bf16 */
+    /* special token ids (Qwen3ASR.swift:54-63,181-193) */
+    int32_t tok_im_start, tok_im_end, tok_audio_start, tok_audio_end, tok_audio_pad, tok_asr_text;
+    int32_t tok_newline, tok_system, tok_user, tok_assistant;
+    /* front-end: 2.0 reproduces vDSP_fft_zrip's documented 2x scaling */
+    float fft_scale;
+    /* engine capacity */
+    int32_t device;                    /* HIP device ordinal */
+    int32_t max_batch;                 /* clips per batch */
+    int32_t max_audio_seconds;         /* longest clip, seconds at 16 kHz (reference cap: 1200) */
+    int32_t max_new_tokens;            /* decoder output cap (reference default 448) */
+    int32_t max_prompt_extra;          /* room for context / language hint tokens in the prompt */
+} qasr_config;
+
+typedef struct qasr_options {
+    int32_t max_tokens;                /* <= config.max_new_tokens; 0 -> 448 */
+    int32_t ignore_eos;                /* 1: always emit max_tokens tokens (fixed-work benchmarking) */
+    const int32_t* context_ids;        /* tokenised context (Qwen3ASR.swift:203-206) or NULL */
+    int32_t n_context;
+    const int32_t* language_ids;       /* tokenised "language XX" hint (:228-232) or NULL */
+    int32_t n_language;
+} qasr_options;
+
+typedef struct qasr_result {
+    const char* text;                  /* owned by the engine, valid until the next call on it */
+    const int32_t* tokens;             /* generated ids incl. the EOS that stopped the loop */
+    int32_t n_tokens;
+} qasr_result;
+
+/* speech-core STT vtable shapes, field order as built at VoicePipeline.swift:376-409 */
+typedef struct sc_transcription_result_t {
+    const char* text;
+    const char* language;
+    float confidence;
+    float start_time;
+    float end_time;
+} sc_transcription_result_t;
+
+typedef struct sc_stt_vtable_t {
+    void* context;
+    sc_transcription_result_t (*transcribe)(void* ctx, const float* audio, size_t length, int sample_rate);
+    int32_t (*input_sample_rate)(void* ctx);
+    void* begin_stream;
+    void* push_chunk;
+    void* flush_stream;
+    void* end_stream;
+    void* cancel_stream;
+} sc_stt_vtable_t;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* preset: "0.6B" | "1.7B" | a model id such as "aufklarer/Qwen3-ASR-0.6B-MLX-4bit"
+ * (size/bits detection of Qwen3ASR.swift:581-601) | "tiny" (test geometry). */
+int qasr_default_config(const char* preset, qasr_config* out);
+/* model_dir: directory with *.safetensors (+ vocab.json, tokenizer_config.json); NULL = create an
+ * empty engine whose tensors arrive through qasr_set_tensor. */
+int qasr_create(const char* model_dir, const qasr_config* cfg, qasr_engine** out);
+int qasr_set_tensor(qasr_engine* e, const char* name, const void* host_data, int dtype,
+                    const int64_t* shape, int ndim);
+int qasr_finalize(qasr_engine* e);                      /* checks completeness, builds fused layouts */
+int qasr_set_vocab(qasr_engine* e, const int32_t* ids, const char* const* tokens, size_t n);
+int qasr_is_loaded(const qasr_engine* e);
+int qasr_unload(qasr_engine* e);
+size_t qasr_memory_footprint(const qasr_engine* e);     /* parameter bytes resident in HBM */
+void qasr_destroy(qasr_engine* e);
+const char* qasr_last_error(const qasr_engine* e);      /* e may be NULL: last create() failure */
+int qasr_input_sample_rate(const qasr_engine* e);       /* 16000 */
+
+/* ---- transcribe --------------------------------------------------------------------------- */
+int qasr_transcribe(qasr_engine* e, const float* pcm, size_t n, int sample_rate,
+                    const qasr_options* opt, qasr_result* out);
+/* tokens: [B, max_new_tokens + 1] row-major, row b = lens[b] ids then padding (-1). */
+int qasr_transcribe_batch(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B,
+                          int sample_rate, const qasr_options* opt, int32_t* tokens, int32_t* lens);
+/* detokenise + "<asr_text>" post-strip (Tokenizer.swift:111-142, Qwen3ASR.swift:283-289);
+ * returns bytes written (excluding NUL) or -1. */
+int qasr_detokenize(qasr_engine* e, const int32_t* tokens, int32_t n, char* buf, size_t cap);
+int qasr_stt_vtable(qasr_engine* e, sc_stt_vtable_t* out);
+
+/* ---- split batch API: H2D / compute / D2H separately timed -------------------------------- */
+int qasr_batch_begin(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B,
+                     const qasr_options* opt);          /* host -> HBM, builds the batch plan */
+int qasr_batch_run(qasr_engine* e);                     /* mel + encoder + prefill + greedy decode, async */
+int qasr_batch_sync(qasr_engine* e);                    /* wait for the engine stream */
+int qasr_batch_tokens(qasr_engine* e, int32_t* tokens, int32_t* lens);   /* HBM -> host */
+/* per-stage device time of the last qasr_batch_run, milliseconds (HIP events on the engine stream):
+ * [0] mel [1] encoder [2] prefill [3] decode [4] total; n_steps = decode steps executed. */
+int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps);
+/* Dominant-kernel probe used by bench.py's roofline object: average duration (ms) of kernel
+ * `which` over the last run measured with HIP events on the engine stream, plus its launch count
+ * and algorithmic bytes per launch.  which: 0 = decode-step weight-streaming GEMV group,
+ * 1 = decode attention, 2 = LM head. */
+int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch);
+
+/* ---- stage entry points (oracle diffing) -------------------------------------------------- */
+int qasr_num_mel_frames(size_t n_samples);              /* frames handed to the encoder */
+int qasr_num_audio_tokens(const qasr_engine* e, int n_frames);
+/* out: [n_mels, T] float32 row-major, T = qasr_num_mel_frames(n) (AudioPreprocessing.swift:315-316) */
+int qasr_mel(qasr_engine* e, const float* pcm, size_t n, float* out);
+/* mel: [n_mels, T] f32 -> out [tokens, enc_out_dim] f32 (bf16 values widened) */
+int qasr_encode(qasr_engine* e, const float* mel, int n_frames, float* out);
+/* audio_embeds [n_audio, hidden] f32 -> logits [vocab] f32 of the prompt's last position; keeps the
+ * KV cache of slot 0 for qasr_decode_forced. */
+int qasr_prefill_logits(qasr_engine* e, const float* audio_embeds, int n_audio,
+                        const qasr_options* opt, float* logits);
+/* teacher-forced steps on slot 0: feeds tokens[i], returns logits [n, vocab]. */
+int qasr_decode_forced(qasr_engine* e, const int32_t* tokens, int n, float* logits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QASR_H */

@@ -1,0 +1,117 @@
+// engine.h -- host-side engine: owns the HIP device/stream, weights, workspaces and the batch plan.
+#pragma once
+#include "common.h"
+#include "mel.h"
+#include "qasr.h"
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace qasr {
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        QASR_HIP(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Pinned host staging buffer
+struct HostBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~HostBuf() { if (p) (void)hipHostFree(p); }
+    void alloc(size_t n) {
+        if (p) (void)hipHostFree(p);
+        if (n == 0) n = 16;
+        QASR_HIP(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Tensor {           // a named parameter resident in HBM
+    DevBuf buf;
+    std::vector<int64_t> shape;
+    int dtype = QASR_DTYPE_BF16;
+    size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
+};
+
+// Per-clip geometry derived on the host (integer work of R2/R4/R7)
+struct ClipPlan {
+    long n_samples = 0;
+    int frames_all = 0;   // incl. the dropped last frame
+    int frames = 0;       // handed to the encoder
+    int n_chunks = 0;
+    int last_chunk_len = 0;
+    int max_chunk_len = 0;      // conv input width for this clip's chunks (100, or <100 for a single short chunk)
+    int n_tokens = 0;     // audio tokens
+    int prompt_len = 0;
+    std::vector<int> windows;   // attention window lengths
+};
+
+class Engine {
+public:
+    explicit Engine(const qasr_config& cfg);
+    ~Engine();
+
+    const qasr_config& config() const { return cfg_; }
+    hipStream_t stream() const { return stream_; }
+    std::string last_error;
+
+    // weights
+    void set_tensor(const std::string& name, const void* host, int dtype, const int64_t* shape, int ndim);
+    void load_directory(const std::string& dir);
+    void finalize();
+    bool loaded() const { return finalized_; }
+    void unload();
+    size_t memory_footprint() const;
+
+    // stages (host in / host out; used by the oracle-diff entry points)
+    void mel_host(const float* pcm, size_t n, float* out);
+
+    static ClipPlan plan_clip(const qasr_config& cfg, long n_samples, int extra_prompt);
+
+private:
+    void upload_pcm(const float* const* pcm, const size_t* n, size_t B);
+    void run_mel();
+
+    qasr_config cfg_;
+    hipStream_t stream_ = nullptr;
+    MelTables mel_tables_;
+    std::map<std::string, Tensor> tensors_;
+    bool finalized_ = false;
+
+    // batch state
+    std::vector<ClipPlan> clips_;
+    long max_samples_ = 0;       // per clip capacity
+    int max_frames_all_ = 0;
+    HostBuf h_pcm_, h_meta_;
+    DevBuf d_pcm_, d_meta_, d_mel_raw_, d_gmax_, d_mel_;
+    int mel_stride_ = 0;
+    // device views into d_meta_ (ints/longs), rebuilt per batch
+    long* d_pcm_off_ = nullptr;
+    int* d_n_samples_ = nullptr;
+    int* d_frame_off_ = nullptr;
+    int batch_ = 0;
+    int batch_max_frames_all_ = 0;
+};
+
+}  // namespace qasr

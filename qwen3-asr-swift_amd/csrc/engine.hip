@@ -1,0 +1,141 @@
+// engine.hip -- engine lifecycle, batch planning, stage orchestration.
+#include "engine.h"
+#include <algorithm>
+#include <cstring>
+
+namespace qasr {
+
+static int conv_len(int n) { return (n - 1) / 2 + 1; }
+static int tokens_for_chunk(int clen) { return conv_len(conv_len(conv_len(clen))); }
+
+// Integer geometry of one clip.  References: AudioPreprocessing.swift:195,296,304 (frames);
+// AudioEncoder.swift:367-380 (chunks), :443-449 (valid tokens), :464-478 (windows);
+// Qwen3ASR.swift:199-233 (prompt length = 16 + tokens + context + language).
+ClipPlan Engine::plan_clip(const qasr_config& cfg, long n, int extra_prompt) {
+    ClipPlan c;
+    c.n_samples = n;
+    c.frames_all = mel_num_frames_all(n);
+    c.frames = mel_num_frames(n);
+    const int chunk = 2 * cfg.n_window;
+    c.n_chunks = (c.frames + chunk - 1) / chunk;
+    int rem = c.frames % chunk;
+    c.last_chunk_len = c.n_chunks == 0 ? 0 : (rem == 0 ? chunk : rem);
+    c.max_chunk_len = c.n_chunks > 1 ? chunk : c.last_chunk_len;
+    c.n_tokens = 0;
+    int max_after = 0;
+    for (int i = 0; i < c.n_chunks; ++i) {
+        int t = tokens_for_chunk(i == c.n_chunks - 1 ? c.last_chunk_len : chunk);
+        c.n_tokens += t;
+        max_after = std::max(max_after, t);
+    }
+    if (c.n_tokens > 0) {
+        int window = max_after * (cfg.n_window_infer / chunk);
+        for (int i = 0; i < c.n_tokens / window; ++i) c.windows.push_back(window);
+        if (c.n_tokens % window) c.windows.push_back(c.n_tokens % window);
+    }
+    c.prompt_len = 16 + c.n_tokens + extra_prompt;
+    return c;
+}
+
+Engine::Engine(const qasr_config& cfg) : cfg_(cfg) {
+    QASR_HIP(hipSetDevice(cfg_.device));
+    QASR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    mel_tables_.build(cfg_.fft_scale);
+    max_samples_ = (long)cfg_.max_audio_seconds * MEL_SR;
+    max_frames_all_ = mel_num_frames_all(max_samples_);
+    const int B = cfg_.max_batch;
+    // pcm: clips back to back, each padded to an even element count
+    h_pcm_.alloc((size_t)B * (max_samples_ + 2) * sizeof(float));
+    d_pcm_.alloc((size_t)B * (max_samples_ + 2) * sizeof(float));
+    h_meta_.alloc((size_t)B * 64);
+    d_meta_.alloc((size_t)B * 64);
+    d_mel_raw_.alloc((size_t)B * max_frames_all_ * MEL_NMELS * sizeof(float));
+    d_gmax_.alloc((size_t)B * sizeof(unsigned));
+    mel_stride_ = ((max_frames_all_ + 63) / 64) * 64;
+    d_mel_.alloc((size_t)B * MEL_NMELS * mel_stride_ * sizeof(float));
+}
+
+Engine::~Engine() {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    mel_tables_.release();
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::set_tensor(const std::string& name, const void* host, int dtype, const int64_t* shape, int ndim) {
+    Tensor& t = tensors_[name];
+    t.shape.assign(shape, shape + ndim);
+    t.dtype = dtype;
+    size_t el = (dtype == QASR_DTYPE_F32 || dtype == QASR_DTYPE_U32) ? 4 : 2;
+    t.buf.alloc(t.numel() * el);
+    QASR_HIP(hipMemcpy(t.buf.p, host, t.numel() * el, hipMemcpyHostToDevice));
+    finalized_ = false;
+}
+
+void Engine::load_directory(const std::string&) { throw std::runtime_error("safetensors loader not built yet"); }
+void Engine::finalize() { finalized_ = true; }
+void Engine::unload() { tensors_.clear(); finalized_ = false; }
+size_t Engine::memory_footprint() const {
+    size_t n = 0;
+    for (auto& kv : tensors_) n += kv.second.buf.bytes;
+    return n;
+}
+
+void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
+    if ((int)B > cfg_.max_batch) throw std::invalid_argument("batch exceeds max_batch");
+    clips_.clear();
+    long off = 0;
+    long* h_off = h_meta_.as<long>();
+    int* h_ns = reinterpret_cast<int*>(h_off + B);
+    int* h_fo = h_ns + B;
+    int frame_off = 0;
+    batch_max_frames_all_ = 0;
+    for (size_t b = 0; b < B; ++b) {
+        if (n[b] == 0) throw std::invalid_argument("empty clip");
+        if ((long)n[b] > max_samples_) throw std::length_error("clip longer than max_audio_seconds");
+        ClipPlan c = plan_clip(cfg_, (long)n[b], 0);
+        std::memcpy(h_pcm_.as<float>() + off, pcm[b], n[b] * sizeof(float));
+        h_off[b] = off;
+        h_ns[b] = (int)n[b];
+        h_fo[b] = frame_off;
+        off += ((long)n[b] + 1) & ~1L;
+        frame_off += c.frames_all;
+        batch_max_frames_all_ = std::max(batch_max_frames_all_, c.frames_all);
+        clips_.push_back(std::move(c));
+    }
+    batch_ = (int)B;
+    QASR_HIP(hipMemcpyAsync(d_pcm_.p, h_pcm_.p, off * sizeof(float), hipMemcpyHostToDevice, stream_));
+    size_t meta_bytes = B * (sizeof(long) + 2 * sizeof(int));
+    QASR_HIP(hipMemcpyAsync(d_meta_.p, h_meta_.p, meta_bytes, hipMemcpyHostToDevice, stream_));
+    d_pcm_off_ = d_meta_.as<long>();
+    d_n_samples_ = reinterpret_cast<int*>(d_pcm_off_ + B);
+    d_frame_off_ = d_n_samples_ + B;
+}
+
+void Engine::run_mel() {
+    MelBatch mb;
+    mb.pcm = d_pcm_.as<float>();
+    mb.pcm_off = d_pcm_off_;
+    mb.n_samples = d_n_samples_;
+    mb.frame_off = d_frame_off_;
+    mb.B = batch_;
+    mb.max_frames_all = batch_max_frames_all_;
+    mb.raw = d_mel_raw_.as<float>();
+    mb.gmax = d_gmax_.as<unsigned>();
+    mb.out = d_mel_.as<float>();
+    mb.out_stride = mel_stride_;
+    mel_launch(mel_tables_, mb, stream_);
+}
+
+void Engine::mel_host(const float* pcm, size_t n, float* out) {
+    const float* ptrs[1] = {pcm};
+    size_t ns[1] = {n};
+    upload_pcm(ptrs, ns, 1);
+    run_mel();
+    int T = clips_[0].frames;
+    if (T > 0)
+        QASR_HIP(hipMemcpy2DAsync(out, (size_t)T * sizeof(float), d_mel_.p, (size_t)mel_stride_ * sizeof(float),
+                                  (size_t)T * sizeof(float), MEL_NMELS, hipMemcpyDeviceToHost, stream_));
+    QASR_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace qasr

@@ -1,0 +1,107 @@
+"""ctypes binding of libqasr.so (the C ABI in include/qasr.h).  No torch types cross it."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libqasr.so")
+
+
+class QasrConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("enc_d_model", "enc_heads", "enc_ffn", "enc_layers", "n_mels",
+                                         "enc_out_dim", "conv_channels", "n_window", "n_window_infer")] + \
+               [("ln_eps", C.c_float)] + \
+               [(n, C.c_int32) for n in ("vocab", "hidden", "dec_layers", "heads", "kv_heads", "head_dim", "inter")] + \
+               [("rms_eps", C.c_float), ("rope_theta", C.c_float), ("group_size", C.c_int32), ("bits", C.c_int32)] + \
+               [(n, C.c_int32) for n in ("tok_im_start", "tok_im_end", "tok_audio_start", "tok_audio_end",
+                                         "tok_audio_pad", "tok_asr_text", "tok_newline", "tok_system",
+                                         "tok_user", "tok_assistant")] + \
+               [("fft_scale", C.c_float)] + \
+               [(n, C.c_int32) for n in ("device", "max_batch", "max_audio_seconds", "max_new_tokens",
+                                         "max_prompt_extra")]
+
+
+class QasrOptions(C.Structure):
+    _fields_ = [("max_tokens", C.c_int32), ("ignore_eos", C.c_int32),
+                ("context_ids", C.POINTER(C.c_int32)), ("n_context", C.c_int32),
+                ("language_ids", C.POINTER(C.c_int32)), ("n_language", C.c_int32)]
+
+
+class QasrResult(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("tokens", C.POINTER(C.c_int32)), ("n_tokens", C.c_int32)]
+
+
+class ScTranscriptionResult(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("language", C.c_char_p), ("confidence", C.c_float),
+                ("start_time", C.c_float), ("end_time", C.c_float)]
+
+
+SC_TRANSCRIBE_FN = C.CFUNCTYPE(ScTranscriptionResult, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int)
+SC_RATE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+
+
+class ScSttVtable(C.Structure):
+    _fields_ = [("context", C.c_void_p), ("transcribe", SC_TRANSCRIBE_FN), ("input_sample_rate", SC_RATE_FN),
+                ("begin_stream", C.c_void_p), ("push_chunk", C.c_void_p), ("flush_stream", C.c_void_p),
+                ("end_stream", C.c_void_p), ("cancel_stream", C.c_void_p)]
+
+
+_P = C.POINTER
+_F = _P(C.c_float)
+_I = _P(C.c_int32)
+_E = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/qasr.h one to one
+SIGNATURES = {
+    "qasr_default_config": (C.c_int, [C.c_char_p, _P(QasrConfig)]),
+    "qasr_create": (C.c_int, [C.c_char_p, _P(QasrConfig), _P(_E)]),
+    "qasr_set_tensor": (C.c_int, [_E, C.c_char_p, C.c_void_p, C.c_int, _P(C.c_int64), C.c_int]),
+    "qasr_finalize": (C.c_int, [_E]),
+    "qasr_set_vocab": (C.c_int, [_E, _I, _P(C.c_char_p), C.c_size_t]),
+    "qasr_is_loaded": (C.c_int, [_E]),
+    "qasr_unload": (C.c_int, [_E]),
+    "qasr_memory_footprint": (C.c_size_t, [_E]),
+    "qasr_destroy": (None, [_E]),
+    "qasr_last_error": (C.c_char_p, [_E]),
+    "qasr_input_sample_rate": (C.c_int, [_E]),
+    "qasr_transcribe": (C.c_int, [_E, _F, C.c_size_t, C.c_int, _P(QasrOptions), _P(QasrResult)]),
+    "qasr_transcribe_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(QasrOptions), _I, _I]),
+    "qasr_detokenize": (C.c_int, [_E, _I, C.c_int32, C.c_char_p, C.c_size_t]),
+    "qasr_stt_vtable": (C.c_int, [_E, _P(ScSttVtable)]),
+    "qasr_batch_begin": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, _P(QasrOptions)]),
+    "qasr_batch_run": (C.c_int, [_E]),
+    "qasr_batch_sync": (C.c_int, [_E]),
+    "qasr_batch_tokens": (C.c_int, [_E, _I, _I]),
+    "qasr_batch_timings": (C.c_int, [_E, _F, _I]),
+    "qasr_kernel_probe": (C.c_int, [_E, C.c_int, C.c_int, _F, _P(C.c_double)]),
+    "qasr_num_mel_frames": (C.c_int, [C.c_size_t]),
+    "qasr_num_audio_tokens": (C.c_int, [_E, C.c_int]),
+    "qasr_mel": (C.c_int, [_E, _F, C.c_size_t, _F]),
+    "qasr_encode": (C.c_int, [_E, _F, C.c_int, _F]),
+    "qasr_prefill_logits": (C.c_int, [_E, _F, C.c_int, _P(QasrOptions), _F]),
+    "qasr_decode_forced": (C.c_int, [_E, _I, C.c_int, _F]),
+}
+
+_lib = None
+
+
+def load(strict=True):
+    """dlopen libqasr.so; raises (never falls back) when the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"libqasr.so not built ({LIB_PATH}); run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing and strict:
+        raise RuntimeError(f"libqasr.so lacks symbols declared in include/qasr.h: {missing}")
+    _lib = lib
+    return lib
