@@ -98,4 +98,12 @@ int qasr_mel(qasr_engine* e, const float* pcm, size_t n, float* out) {
     QASR_GUARD(e, e->impl->mel_host(pcm, n, out));
 }
 
+int qasr_num_audio_tokens(const qasr_engine* e, int n_frames) { return e ? e->impl->num_audio_tokens(n_frames) : -1; }
+
+int qasr_encode(qasr_engine* e, const float* mel, int n_frames, float* out) {
+    if (!e || !mel || !out) return QASR_ERR_INVALID;
+    if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
+    QASR_GUARD(e, e->impl->encode_host(mel, n_frames, out));
+}
+
 }  // extern "C"

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "mel.h"
+#include "enc_kernels.h"
 #include "qasr.h"
 #include <map>
 #include <memory>
@@ -86,12 +87,20 @@ public:
 
     // stages (host in / host out; used by the oracle-diff entry points)
     void mel_host(const float* pcm, size_t n, float* out);
+    void encode_host(const float* mel, int n_frames, float* out);
+    int num_audio_tokens(int n_frames) const;
 
     static ClipPlan plan_clip(const qasr_config& cfg, long n_samples, int extra_prompt);
 
 private:
     void upload_pcm(const float* const* pcm, const size_t* n, size_t B);
     void run_mel();
+    const Tensor& tensor(const std::string& name) const;
+    const bf16_t* wptr(const std::string& name, std::initializer_list<int64_t> shape) const;
+    void finalize_encoder();
+    void alloc_encoder_workspace();
+    void plan_encoder();          // chunk / token / window tables of the current batch -> HBM
+    void run_encoder();
 
     qasr_config cfg_;
     hipStream_t stream_ = nullptr;
@@ -112,6 +121,28 @@ private:
     int* d_frame_off_ = nullptr;
     int batch_ = 0;
     int batch_max_frames_all_ = 0;
+
+    // ---- audio encoder ---------------------------------------------------------------------
+    struct EncLayerW {
+        const bf16_t *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+    };
+    struct EncW {
+        const bf16_t *c1w, *c1b, *c2w, *c2b, *c3w, *c3b, *conv_out, *lnp_g, *lnp_b, *p1w, *p1b, *p2w, *p2b;
+        std::vector<EncLayerW> layers;
+    } encw_;
+    std::vector<std::unique_ptr<DevBuf>> fused_;   // concatenated / permuted copies built by finalize
+    DevBuf d_pe_;                                  // [W3][d_model] f32 sinusoid table
+    int H1_ = 0, W1_ = 0, H2_ = 0, W2_ = 0, H3_ = 0, W3_ = 0;
+    int max_chunks_ = 0, max_tokens_ = 0;          // capacity (whole batch)
+    DevBuf d_c1_, d_c2_, d_c3_, d_encx_, d_ench_, d_encqkv_, d_enca_, d_encmid_, d_audio_;
+    HostBuf h_encmeta_;
+    DevBuf d_encmeta_;
+    ChunkMeta* d_chunks_ = nullptr;
+    long* d_tok_rowoff_ = nullptr;
+    int* d_tok_t_ = nullptr;
+    int* d_cu_win_ = nullptr;
+    int n_img_ = 0, n_tok_ = 0, n_win_ = 0;
+    std::vector<int> clip_tok_off_;                // first packed audio token of each clip
 };
 
 }  // namespace qasr

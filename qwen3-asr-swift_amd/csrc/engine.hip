@@ -72,8 +72,16 @@ void Engine::set_tensor(const std::string& name, const void* host, int dtype, co
 }
 
 void Engine::load_directory(const std::string&) { throw std::runtime_error("safetensors loader not built yet"); }
-void Engine::finalize() { finalized_ = true; }
-void Engine::unload() { tensors_.clear(); finalized_ = false; }
+void Engine::finalize() {
+    finalize_encoder();
+    finalized_ = true;
+}
+void Engine::unload() {
+    QASR_HIP(hipStreamSynchronize(stream_));
+    tensors_.clear();
+    fused_.clear();
+    finalized_ = false;
+}
 size_t Engine::memory_footprint() const {
     size_t n = 0;
     for (auto& kv : tensors_) n += kv.second.buf.bytes;

@@ -1,0 +1,230 @@
+// gemm.h -- bf16 MFMA GEMM  C[M,N] = A[M,K] . W[N,K]^T  (both operands K-contiguous, f32 accumulate)
+// with pluggable A-operand gathers (dense rows / row-offset table / implicit 3x3-stride-2 conv) and
+// fused epilogues.  gfx950 only: v_mfma_f32_16x16x32_bf16, 64-lane waves, XOR-swizzled LDS tiles.
+//
+// Tile: 128 x 128 x 64 per workgroup of 4 waves (2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles).
+// Staging: global_load_dwordx4 -> registers -> ds_write_b128 into a double-buffered LDS image whose
+// 16-byte chunk index is XORed with (row & 7): the MFMA fragment reads (ds_read_b128, 16 rows x one
+// chunk column per 16 lanes) and the staging writes (8 lanes = one 128-byte row) are both
+// bank-conflict free.  Loads for tile k+1 are issued before the MFMAs of tile k and written to LDS
+// after them (one barrier per K-step).  The epilogue goes through LDS so global stores are 16 bytes
+// per lane along rows.
+#pragma once
+#include "common.h"
+
+namespace qasr {
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 64, GEMM_THREADS = 256;
+
+// ------------------------------------------------------------------------------------------------
+// A-operand loaders.  row_init(m) is called once per staged row, load(row, k) once per K-step and
+// must return 8 consecutive bf16 (k .. k+7) or zeros.
+// ------------------------------------------------------------------------------------------------
+struct ADense {
+    const bf16_t* A;
+    long lda;
+    int M, K;
+    struct Row { const bf16_t* p; };
+    __device__ __forceinline__ Row row_init(int m) const { return {m < M ? A + (long)m * lda : nullptr}; }
+    __device__ __forceinline__ uint4 load(const Row& r, int k) const {
+        if (r.p && k < K) return *reinterpret_cast<const uint4*>(r.p + k);
+        return make_uint4(0, 0, 0, 0);
+    }
+};
+
+// rows addressed through an element-offset table (packed valid tokens -> conv3 output rows)
+struct ARowTable {
+    const bf16_t* A;
+    const long* row_off;     // [M] element offsets
+    int M, K;
+    struct Row { const bf16_t* p; };
+    __device__ __forceinline__ Row row_init(int m) const { return {m < M ? A + row_off[m] : nullptr}; }
+    __device__ __forceinline__ uint4 load(const Row& r, int k) const {
+        if (r.p && k < K) return *reinterpret_cast<const uint4*>(r.p + k);
+        return make_uint4(0, 0, 0, 0);
+    }
+};
+
+// Implicit GEMM for a 3x3 / stride 2 / pad 1 convolution over NHWC bf16 input [img][H][W][C].
+// K index = (kh*3 + kw) * C + ci  (the reference's MLX weight layout [out][kh][kw][in],
+// Sources/Qwen3ASR/WeightLoading.swift:284).  Output pixel order: hw_major ? m = (img*OH+oh)*OW+ow
+// : m = (img*OW+ow)*OH+oh  (the latter makes conv3's rows directly the conv_out operand).
+struct AConv3x3s2 {
+    const bf16_t* in;
+    int H, W, C, OH, OW, M, K;
+    bool hw_major;
+    struct Row { const bf16_t* base; unsigned mask; };   // base = pixel (2oh-1, 2ow-1); mask bit t = tap valid
+    __device__ __forceinline__ Row row_init(int m) const {
+        if (m >= M) return {nullptr, 0u};
+        int img = m / (OH * OW), rem = m - img * (OH * OW);
+        int oh, ow;
+        if (hw_major) { oh = rem / OW; ow = rem - oh * OW; } else { ow = rem / OH; oh = rem - ow * OH; }
+        int ih0 = 2 * oh - 1, iw0 = 2 * ow - 1;
+        unsigned mask = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int ih = ih0 + kh, iw = iw0 + kw;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W) mask |= 1u << (kh * 3 + kw);
+            }
+        return {in + (((long)img * H + ih0) * W + iw0) * C, mask};
+    }
+    __device__ __forceinline__ uint4 load(const Row& r, int k) const {
+        if (k >= K) return make_uint4(0, 0, 0, 0);
+        int tap = k / C, ci = k - tap * C;
+        if (!((r.mask >> tap) & 1u)) return make_uint4(0, 0, 0, 0);
+        int kh = tap / 3, kw = tap - kh * 3;
+        return *reinterpret_cast<const uint4*>(r.base + ((long)kh * W + kw) * C + ci);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernel
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+__device__ __forceinline__ int gemm_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <class ALoad, class Epi>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw,
+                                                                int M, int N, int K, Epi epi) {
+    __shared__ __attribute__((aligned(16))) char smem[2][2][GEMM_BM * 128];   // [buf][A|B][row*128B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: consecutive tile ids (sharing an A row panel) land on one XCD's L2
+    const int nbx = (N + GEMM_BN - 1) / GEMM_BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / nbx) * GEMM_BM, n0 = (bid % nbx) * GEMM_BN;
+
+    const int sc = tid & 7, sr = tid >> 3;             // staged chunk column / first staged row
+    typename ALoad::Row arow[4];
+    const bf16_t* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        arow[i] = aload.row_init(m0 + sr + 32 * i);
+        int n = n0 + sr + 32 * i;
+        wrow[i] = n < N ? Wt + (long)n * ldw : nullptr;
+    }
+    uint4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int k = kt * GEMM_BK + sc * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = aload.load(arow[i], k);
+            rb[i] = (wrow[i] && k < K) ? *reinterpret_cast<const uint4*>(wrow[i] + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int off = gemm_lds_off(sr + 32 * i, sc);
+            *reinterpret_cast<uint4*>(&smem[buf][0][off]) = ra[i];
+            *reinterpret_cast<uint4*>(&smem[buf][1][off]) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fc = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            mfma_bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][0][gemm_lds_off(wm * 64 + i * 16 + fr, fc + 4 * s)]);
+                b[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][1][gemm_lds_off(wn * 64 + i * 16 + fr, fc + 4 * s)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: wave-private 64x64 f32 image, then 16-byte row stores -----------
+    float* ct = reinterpret_cast<float*>(&smem[0][0][0]) + wave * (64 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        int row = it * 4 + er;
+        int m = m0 + wm * 64 + row, n = n0 + wn * 64 + ec;
+        if (m < M && n < N) {
+            float4 v = *reinterpret_cast<const float4*>(&ct[row * 64 + ec]);
+            epi(m, n, v);
+        }
+    }
+}
+
+template <class ALoad, class Epi>
+inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogues: operator()(m, n, float4 acc[n..n+3])   (N is always a multiple of 4)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    return o;
+}
+__device__ __forceinline__ float4 load_bf16x4(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_to_f32((bf16_t)(u.x & 0xffff)), bf16_to_f32((bf16_t)(u.x >> 16)),
+                       bf16_to_f32((bf16_t)(u.y & 0xffff)), bf16_to_f32((bf16_t)(u.y >> 16)));
+}
+
+// out_bf16[m][n] = act(acc + bias[n]);  ACT: 0 none, 1 exact GELU
+template <int ACT>
+struct EpiBiasActBf16 {
+    bf16_t* out; long ldo; const bf16_t* bias;   // bias may be null
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
+        if (bias) { float4 b = load_bf16x4(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        *reinterpret_cast<uint2*>(out + (long)m * ldo + n) = pack_bf16x4(v);
+    }
+};
+
+// x_f32[m][n] += acc + bias[n]   (encoder residual stream, f32)
+struct EpiResidF32 {
+    float* x; long ldx; const bf16_t* bias;
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
+        float4 b = load_bf16x4(bias + n);
+        float4* p = reinterpret_cast<float4*>(x + (long)m * ldx + n);
+        float4 r = *p;
+        r.x += v.x + b.x; r.y += v.y + b.y; r.z += v.z + b.z; r.w += v.w + b.w;
+        *p = r;
+    }
+};
+
+}  // namespace qasr
