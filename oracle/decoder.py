@@ -68,14 +68,42 @@ class DecoderState:
         return 0 if self.k[0] is None else self.k[0].shape[1]
 
 
+def flash_prefill_attention(qh, kh, vh, scale, off, tile=64):
+    """Restatement of the HIP prompt-pass attention (csrc/dec_kernels.hip: prefill_attention_kernel):
+    online softmax over key tiles of `tile`, un-normalised P rounded to bf16 before P.V, running
+    sum taken over the rounded P, one division at the end.  qh [H, T, hd], kh/vh [H, ctx, hd].
+    The reference's own SDPA internals (MLXFast, not in its tree) are unobservable; this is the
+    DEVICE policy, compared against the plain-softmax REFERENCE policy with a stated tolerance."""
+    H, T, hd = qh.shape
+    ctx = kh.shape[1]
+    row = (torch.arange(T) + off)[:, None]
+    m = torch.full((H, T), float("-inf"))
+    l = torch.zeros(H, T)
+    o = torch.zeros(H, T, hd)
+    for k0 in range(0, ctx, tile):
+        k1 = min(k0 + tile, ctx)
+        s = (qh @ kh[:, k0:k1].transpose(1, 2)) * scale
+        col = torch.arange(k0, k1)[None, :]
+        s = torch.where((col <= row)[None], s, torch.tensor(float("-inf")))
+        m_new = torch.maximum(m, s.max(dim=-1).values)
+        m_ref = torch.where(torch.isinf(m_new), torch.zeros_like(m_new), m_new)
+        alpha = torch.exp(m - m_ref)
+        p = P.bf16_round(torch.exp(s - m_ref[..., None]))
+        l = l * alpha + p.sum(dim=-1)
+        o = o * alpha[..., None] + p @ vh[:, k0:k1]
+        m = m_new
+    return o / l[..., None]
+
+
 def forward(embeds, W: Weights, cfg: TextDecoderConfig, state: DecoderState, pol: P.Policy,
             p_bf16=None):
     """embeds [T, hidden] (already in decoder dtype) -> final-normed hidden [T, hidden]."""
     T = embeds.shape[0]
     off = state.length
     pos = torch.arange(off, off + T)
+    flash = pol.name == "device" and T > 1
     if p_bf16 is None:
-        p_bf16 = pol.dec_bf16 and T > 1       # MFMA prefill rounds P; the T_q=1 path keeps f32
+        p_bf16 = False                        # plain softmax keeps f32 probabilities (MLX SDPA)
     scale = 1.0 / math.sqrt(cfg.head_dim)
     rep = cfg.heads // cfg.kv_heads
     x = embeds
@@ -98,15 +126,19 @@ def forward(embeds, W: Weights, cfg: TextDecoderConfig, state: DecoderState, pol
         qh = q.transpose(0, 1)                                     # [heads, T, hd]
         kh = kT.repeat_interleave(rep, dim=0)
         vh = vT.repeat_interleave(rep, dim=0)
-        sc = (qh @ kh.transpose(1, 2)) * scale                     # [heads, T, ctx]
-        if T > 1:
-            col = torch.arange(ctx)[None, :]
-            row = (torch.arange(T) + off)[:, None]
-            sc = sc + torch.where(col > row, torch.tensor(-1e9), torch.tensor(0.0))[None]
-        pr = torch.softmax(sc, dim=-1)
-        if p_bf16:
-            pr = P.bf16_round(pr)
-        a = pol.dec(pr @ vh).transpose(0, 1).reshape(T, cfg.heads * cfg.head_dim)
+        if flash:
+            av = flash_prefill_attention(qh, kh, vh, scale, off)
+        else:
+            sc = (qh @ kh.transpose(1, 2)) * scale                 # [heads, T, ctx]
+            if T > 1:
+                col = torch.arange(ctx)[None, :]
+                row = (torch.arange(T) + off)[:, None]
+                sc = sc + torch.where(col > row, torch.tensor(-1e9), torch.tensor(0.0))[None]
+            pr = torch.softmax(sc, dim=-1)
+            if p_bf16:
+                pr = P.bf16_round(pr)
+            av = pr @ vh
+        a = pol.dec(av).transpose(0, 1).reshape(T, cfg.heads * cfg.head_dim)
         x = pol.dec(x + pol.dec(a @ W(p + ".self_attn.o_proj.weight").T))
         h = rms_norm(x, W(p + ".post_attention_layernorm.weight"), cfg.rms_eps, pol)
         g = pol.dec(h @ W(p + ".mlp.gate_proj.weight").T)

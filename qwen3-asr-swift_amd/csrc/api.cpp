@@ -2,6 +2,7 @@
 #include "engine.h"
 #include <cstring>
 #include <string>
+#include <vector>
 
 using qasr::Engine;
 
@@ -104,6 +105,112 @@ int qasr_encode(qasr_engine* e, const float* mel, int n_frames, float* out) {
     if (!e || !mel || !out) return QASR_ERR_INVALID;
     if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
     QASR_GUARD(e, e->impl->encode_host(mel, n_frames, out));
+}
+
+int qasr_set_vocab(qasr_engine* e, const int32_t* ids, const char* const* tokens, size_t n) {
+    if (!e || !ids || !tokens) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->set_vocab(ids, tokens, n));
+}
+
+int qasr_detokenize(qasr_engine* e, const int32_t* tokens, int32_t n, char* buf, size_t cap) {
+    if (!e || !tokens || !buf || cap == 0 || n < 0) return -1;
+    try {
+        std::string t = e->impl->detokenize(tokens, n, true);
+        if (t.size() + 1 > cap) { fail(e, QASR_ERR_CAPACITY, "detokenize: buffer too small"); return -1; }
+        std::memcpy(buf, t.c_str(), t.size() + 1);
+        return (int)t.size();
+    } catch (const std::exception& ex) { fail(e, QASR_ERR_INVALID, ex.what()); return -1; }
+}
+
+int qasr_batch_begin(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B, const qasr_options* opt) {
+    if (!e || !pcm || !n) return QASR_ERR_INVALID;
+    if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
+    for (size_t b = 0; b < B; ++b) if (n[b] == 0 || !pcm[b]) return fail(e, QASR_ERR_EMPTY_AUDIO, "empty clip in batch");
+    QASR_GUARD(e, e->impl->batch_begin(pcm, n, B, opt));
+}
+int qasr_batch_run(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_run()); }
+int qasr_batch_sync(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_sync()); }
+int qasr_batch_tokens(qasr_engine* e, int32_t* tokens, int32_t* lens) {
+    if (!e || !tokens || !lens) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->batch_tokens(tokens, lens));
+}
+int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps) {
+    if (!e || !ms) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->batch_timings(ms, n_steps));
+}
+int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch) {
+    if (!e || !avg_ms || !bytes_per_launch || reps <= 0 || which < 0 || which > 2) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->kernel_probe(which, reps, avg_ms, bytes_per_launch));
+}
+
+int qasr_transcribe_batch(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
+                          const qasr_options* opt, int32_t* tokens, int32_t* lens) {
+    if (!e || !tokens || !lens) return QASR_ERR_INVALID;
+    // AudioPreprocessing.swift:327-329 resamples with AVAudioConverter (closed source); inputs must be 16 kHz here
+    if (sample_rate != 16000) return fail(e, QASR_ERR_INVALID, "only 16 kHz input is supported (resampler is out of scope)");
+    int rc = qasr_batch_begin(e, pcm, n, B, opt);
+    if (rc) return rc;
+    if ((rc = qasr_batch_run(e))) return rc;
+    return qasr_batch_tokens(e, tokens, lens);
+}
+
+int qasr_transcribe(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const qasr_options* opt, qasr_result* out) {
+    if (!e || !out) return QASR_ERR_INVALID;
+    const int stride = e->impl->config().max_new_tokens + 1;
+    std::vector<int32_t> toks((size_t)stride);
+    int32_t len = 0;
+    const float* ptrs[1] = {pcm};
+    size_t ns[1] = {n};
+    int rc = qasr_transcribe_batch(e, ptrs, ns, 1, sample_rate, opt, toks.data(), &len);
+    if (rc) return rc;
+    try {
+        e->impl->result_tokens.assign(toks.begin(), toks.begin() + len);
+        e->impl->result_text = e->impl->detokenize(toks.data(), len, true);
+    } catch (const std::exception& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); }
+    out->text = e->impl->result_text.c_str();
+    out->tokens = e->impl->result_tokens.data();
+    out->n_tokens = len;
+    return QASR_OK;
+}
+
+// speech-core bridge (VoicePipeline.swift:374-410): strings stay valid until the next transcribe
+static sc_transcription_result_t vt_transcribe(void* ctx, const float* audio, size_t length, int sample_rate) {
+    qasr_engine* e = static_cast<qasr_engine*>(ctx);
+    qasr_result r{};
+    sc_transcription_result_t out{};
+    int rc = qasr_transcribe(e, audio, length, sample_rate, nullptr, &r);
+    if (rc != QASR_OK) {
+        e->impl->result_text = std::string("[qasr error: ") + e->impl->last_error + "]";
+        out.text = e->impl->result_text.c_str();
+    } else {
+        out.text = r.text;
+    }
+    out.language = "";
+    out.confidence = 0.0f;      // TranscriptionResult default (Protocols.swift:141)
+    out.start_time = 0.0f;
+    out.end_time = 0.0f;
+    return out;
+}
+static int32_t vt_rate(void*) { return 16000; }
+
+int qasr_stt_vtable(qasr_engine* e, sc_stt_vtable_t* out) {
+    if (!e || !out) return QASR_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->context = e;
+    out->transcribe = vt_transcribe;
+    out->input_sample_rate = vt_rate;
+    return QASR_OK;
+}
+
+int qasr_prefill_logits(qasr_engine* e, const float* audio_embeds, int n_audio, const qasr_options* opt, float* logits) {
+    if (!e || !logits || (n_audio > 0 && !audio_embeds)) return QASR_ERR_INVALID;
+    if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
+    QASR_GUARD(e, e->impl->prefill_logits_host(audio_embeds, n_audio, opt, logits));
+}
+
+int qasr_decode_forced(qasr_engine* e, const int32_t* tokens, int n, float* logits) {
+    if (!e || !tokens || !logits || n < 0) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->decode_forced_host(tokens, n, logits));
 }
 
 }  // extern "C"

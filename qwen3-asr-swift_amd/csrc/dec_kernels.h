@@ -1,0 +1,103 @@
+// dec_kernels.h -- text-decoder kernels (Qwen3 decoder-only LM with GQA, q/k RMSNorm, split-half
+// RoPE, SwiGLU, tied LM head).  Reference: Sources/Qwen3ASR/QuantizedTextDecoder.swift:56-251,
+// FloatTextDecoder.swift:35-226, Qwen3ASR.swift:236-256,317-390.
+//
+// bf16 at every op boundary like the reference's MLX tensors (see oracle/precision.py), f32 inside.
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace qasr {
+
+// ---- shared small kernels -------------------------------------------------------------------
+// y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps)))  over rows of width H (bf16 in / bf16 out)
+void rmsnorm_rows_launch(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps, hipStream_t s);
+
+// x[p] = audio_src[p] >= 0 ? audio[audio_src[p]] : embed[ids[p]]      (Qwen3ASR.swift:236-244)
+void embed_splice_launch(const int* ids, const int* audio_src, const bf16_t* embed, const bf16_t* audio, bf16_t* x,
+                         int n_pos, int H, hipStream_t s);
+
+// gather rows: dst[i] = src[row_idx[i]]
+void gather_rows_launch(const bf16_t* src, const int* row_idx, bf16_t* dst, int n, int H, hipStream_t s);
+
+// ---- prefill -------------------------------------------------------------------------------------
+struct KVLayout {          // one layer's cache: K/V [slot][kv_head][max_ctx][hd] bf16
+    bf16_t* k;
+    bf16_t* v;
+    int max_ctx, kv_heads, hd;
+    __host__ __device__ long off(int slot, int kvh, int pos) const {
+        return (((long)slot * kv_heads + kvh) * max_ctx + pos) * hd;
+    }
+};
+
+// Per packed prompt position p: q/k RMSNorm over head_dim, RoPE at position pos[p], then
+//   q  -> qr[p][head][hd]; k -> cache.k[slot][kvh][pos]; v -> cache.v[...] and vt[slot][kvh][d][pos]
+// qkv: [n_pos][(heads + 2 kv) * hd]  (q | k | v).   rope tables: [max_pos][hd/2] f32.
+void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads,
+                         int hd, const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
+                         const float* rope_sin, bf16_t* qr, KVLayout cache, bf16_t* vt, int vt_stride,
+                         hipStream_t s);
+
+// Causal flash attention over packed prompts.  clip c occupies packed rows [cu[c], cu[c+1]).
+// Online softmax in key tiles of 64 with unnormalised P rounded to bf16 (restated in
+// oracle/decoder.py: flash_prefill_attention).  out: [n_pos][heads*hd] bf16.
+void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt, int vt_stride, const int* cu,
+                              const int* slot_of_clip, int n_clips, int max_len, int heads, bf16_t* out,
+                              hipStream_t s);
+
+// ---- decode step (M = batch rows) -----------------------------------------------------------------
+enum DecEpi { DEC_EPI_BF16 = 0, DEC_EPI_RESID = 1, DEC_EPI_SWIGLU = 2, DEC_EPI_LOGITS = 3 };
+
+struct DecGemvArgs {
+    const bf16_t* W;       // [N][K] row-major
+    const bf16_t* X;       // [B][K] bf16 activations
+    int B, N, K;
+    bf16_t* out;           // BF16: [B][N]; RESID: x in place [B][N]; SWIGLU: [B][N/2]
+    float* logits;         // LOGITS: optional [B][N] f32 (bf16-rounded values), may be null
+    float* part_val;       // LOGITS: [B][n_blocks]
+    int* part_idx;         // LOGITS: [B][n_blocks]
+};
+// Weight-streaming skinny GEMM: every weight byte is read once, straight into MFMA A fragments.
+// Returns the number of workgroups (LOGITS: partial count per row).
+int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s);
+int decode_gemv_blocks(DecEpi epi, int N);
+
+// One new token per batch row: q/k norm + RoPE at pos = ctx_len[b], append K/V to the cache,
+// attention of the rep = heads/kv_heads query heads over the cache (f32 softmax), out [B][heads*hd].
+void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int heads, int kv_heads, int hd,
+                             const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
+                             const float* rope_sin, KVLayout cache, bf16_t* out, hipStream_t s);
+
+// Greedy bookkeeping after the LM head (Qwen3ASR.swift:336-388): argmax over the per-block partials
+// (lowest index wins ties, like MLX argMax), append the token unless the row is finished, mark EOS /
+// length-cap, advance ctx_len (decode steps), and gather the next input embedding.
+struct GreedyState {
+    int* tokens;        // [B][max_new + 1]
+    int* lens;          // [B]
+    int* finished;      // [B]
+    int* ctx_len;       // [B]
+    int* n_active;      // [1] rows not finished
+    int max_new;        // row stride - 1
+    int max_tokens;     // cap for this batch
+    int eos;
+    int ignore_eos;
+};
+void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
+                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, hipStream_t s);
+
+// ---- epilogues for the prefill GEMMs ----------------------------------------------------------------
+// x_bf16[m][n] = bf16(x + bf16(acc))   (residual add in the decoder dtype)
+struct EpiResidBf16 {
+    bf16_t* x; long ldx;
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
+        bf16_t* p = x + (long)m * ldx + n;
+        float4 r = load_bf16x4(p);
+        r.x += bf16_round(v.x); r.y += bf16_round(v.y); r.z += bf16_round(v.z); r.w += bf16_round(v.w);
+        *reinterpret_cast<uint2*>(p) = pack_bf16x4(r);
+    }
+};
+
+// QuantizedTextDecoder.swift:134-136 with bf16 tensors: silu(gate) -> bf16, * up -> bf16
+__device__ __forceinline__ float swiglu_bf16(float g_acc, float u_acc) { return gemm_swiglu(g_acc, u_acc); }
+
+}  // namespace qasr

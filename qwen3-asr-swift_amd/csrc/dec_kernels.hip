@@ -1,0 +1,732 @@
+// dec_kernels.hip -- text-decoder kernels (see dec_kernels.h).
+#include "dec_kernels.h"
+
+namespace qasr {
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm rows: one wavefront per row.  y = bf16(w * bf16(x * inv)), inv = rsqrt(mean(x^2) + eps)
+// ------------------------------------------------------------------------------------------------
+constexpr int RMS_MAXV = 4;   // 8-element chunks per lane: H <= 2048
+
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ y, int rows, int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nch = H / 8;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (long)row * H);
+    uint4 v[RMS_MAXV];
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAXV; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < nch ? xr[c] : make_uint4(0, 0, 0, 0);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
+    }
+    const float inv = rsqrtf(wave_sum(ss) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < RMS_MAXV; ++i) {
+        int c = lane + 64 * i;
+        if (c < nch) {
+            uint4 wv = reinterpret_cast<const uint4*>(w)[c];
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[i]);
+            const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
+            uint4 o;
+            bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oe[j] = f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv));
+            reinterpret_cast<uint4*>(y + (long)row * H)[c] = o;
+        }
+    }
+}
+
+void rmsnorm_rows_launch(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps, hipStream_t s) {
+    if (rows <= 0) return;
+    if (H % 8 != 0 || H > 512 * RMS_MAXV) throw std::invalid_argument("rmsnorm: unsupported width");
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, y, rows, H, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding lookup with audio splice; row gather
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_splice_kernel(const int* __restrict__ ids, const int* __restrict__ audio_src,
+                                    const bf16_t* __restrict__ embed, const bf16_t* __restrict__ audio,
+                                    bf16_t* __restrict__ x, int H) {
+    const int p = blockIdx.x;
+    const int a = audio_src[p];
+    const uint4* src = reinterpret_cast<const uint4*>(a >= 0 ? audio + (long)a * H : embed + (long)ids[p] * H);
+    uint4* dst = reinterpret_cast<uint4*>(x + (long)p * H);
+    for (int i = threadIdx.x; i < H / 8; i += blockDim.x) dst[i] = src[i];
+}
+
+void embed_splice_launch(const int* ids, const int* audio_src, const bf16_t* embed, const bf16_t* audio, bf16_t* x,
+                         int n_pos, int H, hipStream_t s) {
+    if (n_pos <= 0) return;
+    hipLaunchKernelGGL(embed_splice_kernel, dim3(n_pos), dim3(128), 0, s, ids, audio_src, embed, audio, x, H);
+}
+
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, bf16_t* __restrict__ dst, int H) {
+    const uint4* s = reinterpret_cast<const uint4*>(src + (long)idx[blockIdx.x] * H);
+    uint4* d = reinterpret_cast<uint4*>(dst + (long)blockIdx.x * H);
+    for (int i = threadIdx.x; i < H / 8; i += blockDim.x) d[i] = s[i];
+}
+
+void gather_rows_launch(const bf16_t* src, const int* row_idx, bf16_t* dst, int n, int H, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(128), 0, s, src, row_idx, dst, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// q/k RMSNorm + RoPE + cache write for packed prompt positions.  One wavefront per (position, head).
+// Lane l owns the rotation pair (l, l + hd/2).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void norm_rope_pair(float x1, float x2, float w1, float w2, float inv, float c, float sn,
+                                               float& o1, float& o2) {
+    // bf16(w * bf16(x * inv))  then  bf16(x1*cos - x2*sin), bf16(x1*sin + x2*cos)
+    float y1 = bf16_round(w1 * bf16_round(x1 * inv));
+    float y2 = bf16_round(w2 * bf16_round(x2 * inv));
+    o1 = bf16_round(y1 * c - y2 * sn);
+    o2 = bf16_round(y1 * sn + y2 * c);
+}
+
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ slot,
+                                                           const int* __restrict__ pos, int n_pos, int heads,
+                                                           int kv_heads, int hd, const bf16_t* __restrict__ qn_w,
+                                                           const bf16_t* __restrict__ kn_w, float eps,
+                                                           const float* __restrict__ rope_cos,
+                                                           const float* __restrict__ rope_sin, bf16_t* __restrict__ qr,
+                                                           KVLayout cache, bf16_t* __restrict__ vt, int vt_stride) {
+    const int nh = heads + 2 * kv_heads;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long)n_pos * nh) return;
+    const int p = (int)(wid / nh), h = (int)(wid - (long)p * nh);
+    const int half = hd / 2;
+    const bf16_t* src = qkv + (long)p * nh * hd + (long)h * hd;
+    const int sl = slot[p], ps = pos[p];
+    const bool act = lane < half;
+    if (h >= heads + kv_heads) {                      // V: plain copy into both layouts
+        const int kvh = h - heads - kv_heads;
+        if (act) {
+            bf16_t a = src[lane], b = src[lane + half];
+            bf16_t* dv = cache.v + cache.off(sl, kvh, ps);
+            dv[lane] = a;
+            dv[lane + half] = b;
+            if (vt) {
+                bf16_t* t = vt + ((long)sl * kv_heads + kvh) * hd * vt_stride + ps;
+                t[(long)lane * vt_stride] = a;
+                t[(long)(lane + half) * vt_stride] = b;
+            }
+        }
+        return;
+    }
+    float x1 = act ? bf16_to_f32(src[lane]) : 0.0f, x2 = act ? bf16_to_f32(src[lane + half]) : 0.0f;
+    const float inv = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)hd + eps);
+    if (!act) return;
+    const bf16_t* nw = h < heads ? qn_w : kn_w;
+    float c = rope_cos[(long)ps * half + lane], sn = rope_sin[(long)ps * half + lane];
+    float o1, o2;
+    norm_rope_pair(x1, x2, bf16_to_f32(nw[lane]), bf16_to_f32(nw[lane + half]), inv, c, sn, o1, o2);
+    bf16_t* dst = h < heads ? qr + ((long)p * heads + h) * hd : cache.k + cache.off(sl, h - heads, ps);
+    dst[lane] = f32_to_bf16(o1);
+    dst[lane + half] = f32_to_bf16(o2);
+}
+
+void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads, int hd,
+                         const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
+                         const float* rope_sin, bf16_t* qr, KVLayout cache, bf16_t* vt, int vt_stride, hipStream_t s) {
+    if (n_pos <= 0) return;
+    if (hd > 128 || hd % 2) throw std::invalid_argument("head_dim must be even and <= 128");
+    long waves = (long)n_pos * (heads + 2 * kv_heads);
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
+                       kv_heads, hd, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache, vt, vt_stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Causal flash attention for the prompt pass.  Workgroup = 128 query rows of one (clip, head):
+// 4 waves x 32 rows (2 MFMA row tiles).  Key tiles of 64: K rows and V^T rows are staged in LDS with
+// an XOR chunk swizzle, S = Q K^T (16x16x32 MFMA), online softmax on the accumulator layout (a row
+// lives on 16 lanes), P -> bf16 through a wave-private LDS image -> A operand of P V.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __restrict__ qr, KVLayout cache,
+                                                                const bf16_t* __restrict__ vt, int vt_stride,
+                                                                const int* __restrict__ cu,
+                                                                const int* __restrict__ slot_of_clip, int heads,
+                                                                bf16_t* __restrict__ out, float scale) {
+    constexpr int KT = 64;                 // keys per tile
+    constexpr int KCH = HD / 8;            // 16-byte chunks per K row
+    constexpr int KS = HD / 32;            // k-steps of Q K^T
+    constexpr int DT = HD / 16;            // output d tiles
+    constexpr int PLD = KT + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t s_k[KT * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t s_v[HD * KT];
+    __shared__ __attribute__((aligned(16))) bf16_t s_p[4][32][PLD];
+    const int clip = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int row0 = cu[clip], T = cu[clip + 1] - row0;
+    if (q0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    const int sl = slot_of_clip[clip];
+    const int kvh = h / (heads / cache.kv_heads);
+    const bf16_t* kbase = cache.k + cache.off(sl, kvh, 0);
+    const bf16_t* vbase = vt + ((long)sl * cache.kv_heads + kvh) * HD * vt_stride;
+    const int qw = q0 + wave * 32;         // first query row of this wave
+
+    mfma_bf16x8 qf[2][KS];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = qw + mi * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (r < T) u = *reinterpret_cast<const uint4*>(qr + ((long)(row0 + r) * heads + h) * HD + s * 32 + fc * 8);
+            qf[mi][s] = __builtin_bit_cast(mfma_bf16x8, u);
+        }
+    }
+    f32x4 o[2][DT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[mi][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2][4], l_run[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m_run[mi][j] = -INFINITY; l_run[mi][j] = 0.0f; }
+
+    const int q_hi = min(q0 + 128, T);                 // causal: keys < q_hi
+    const int n_tiles = (q_hi + KT - 1) / KT;
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int k0 = kt * KT;
+        __syncthreads();                               // previous tile's reads are done
+        for (int i = tid; i < KT * KCH; i += 256) {    // K rows [key][HD], chunk ^ (key & (KCH-1))
+            int key = i / KCH, ch = i - key * KCH;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (k0 + key < T) u = *reinterpret_cast<const uint4*>(kbase + (long)(k0 + key) * HD + ch * 8);
+            *reinterpret_cast<uint4*>(&s_k[key * HD + ((ch ^ (key & (KCH - 1))) << 3)]) = u;
+        }
+        for (int i = tid; i < HD * (KT / 8); i += 256) {   // V^T rows [d][KT], chunk ^ (d & 7)
+            int d = i / (KT / 8), ch = i - d * (KT / 8);
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (k0 + ch * 8 < T) u = *reinterpret_cast<const uint4*>(vbase + (long)d * vt_stride + k0 + ch * 8);
+            *reinterpret_cast<uint4*>(&s_v[d * KT + ((ch ^ (d & 7)) << 3)]) = u;
+        }
+        __syncthreads();
+        if (k0 <= qw + 31 && qw < T) {                 // this wave has unmasked keys in the tile
+            f32x4 sc[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                mfma_bf16x8 kf[KS];
+                const int key = nt * 16 + fr;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    kf[s] = *reinterpret_cast<const mfma_bf16x8*>(&s_k[key * HD + (((s * 4 + fc) ^ (key & (KCH - 1))) << 3)]);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[mi][s], kf[s], acc, 0, 0, 0);
+                    sc[mi][nt] = acc;
+                }
+            }
+            // online softmax; lane holds rows mi*16 + fc*4 + j, key column nt*16 + fr
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float alpha[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qpos = qw + mi * 16 + fc * 4 + j;
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int key = k0 + nt * 16 + fr;
+                        float v = (key <= qpos && key < T) ? sc[mi][nt][j] * scale : -INFINITY;
+                        sc[mi][nt][j] = v;
+                        mx = fmaxf(mx, v);
+                    }
+#pragma unroll
+                    for (int ofs = 1; ofs < 16; ofs <<= 1) mx = fmaxf(mx, __shfl_xor(mx, ofs, 64));
+                    const float m_new = fmaxf(m_run[mi][j], mx);
+                    // rows with no visible key yet keep m = -inf: use 0 as the reference to avoid inf - inf
+                    const float m_ref = m_new == -INFINITY ? 0.0f : m_new;
+                    alpha[j] = expf(m_run[mi][j] - m_ref);
+                    float rs = 0.0f;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        bf16_t pb = f32_to_bf16(expf(sc[mi][nt][j] - m_ref));
+                        s_p[wave][mi * 16 + fc * 4 + j][nt * 16 + fr] = pb;
+                        rs += bf16_to_f32(pb);
+                    }
+#pragma unroll
+                    for (int ofs = 1; ofs < 16; ofs <<= 1) rs += __shfl_xor(rs, ofs, 64);
+                    l_run[mi][j] = l_run[mi][j] * alpha[j] + rs;
+                    m_run[mi][j] = m_new;
+                }
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[mi][d][j] *= alpha[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < KT / 32; ++ks) {
+                mfma_bf16x8 pa[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    pa[mi] = *reinterpret_cast<const mfma_bf16x8*>(&s_p[wave][mi * 16 + fr][ks * 32 + fc * 8]);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int dr = d * 16 + fr;
+                    mfma_bf16x8 vf = *reinterpret_cast<const mfma_bf16x8*>(&s_v[dr * KT + (((ks * 4 + fc) ^ (dr & 7)) << 3)]);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) o[mi][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[mi], vf, o[mi][d], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = qw + mi * 16 + fc * 4 + j;
+            if (r < T) {
+                const float invl = 1.0f / l_run[mi][j];
+                bf16_t* dst = out + ((long)(row0 + r) * heads + h) * HD;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) dst[d * 16 + fr] = f32_to_bf16(o[mi][d][j] * invl);
+            }
+        }
+}
+
+void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt, int vt_stride, const int* cu,
+                              const int* slot_of_clip, int n_clips, int max_len, int heads, bf16_t* out,
+                              hipStream_t s) {
+    if (n_clips <= 0 || max_len <= 0) return;
+    dim3 grid(cdiv(max_len, 128), heads, n_clips);
+    const float scale = 1.0f / sqrtf((float)cache.hd);
+    if (cache.hd == 128)
+        hipLaunchKernelGGL(prefill_attention_kernel<128>, grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu,
+                           slot_of_clip, heads, out, scale);
+    else if (cache.hd == 32)
+        hipLaunchKernelGGL(prefill_attention_kernel<32>, grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu,
+                           slot_of_clip, heads, out, scale);
+    else
+        throw std::invalid_argument("prefill attention: head_dim must be 32 or 128");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode-step skinny GEMM:  out[b][n] = sum_k X[b][k] W[n][k],  b < B <= 16*NB.
+// Workgroup = 4 waves over 16*NT weight rows; wave w takes k-steps w, w+4, ... of 32 columns.  The
+// weight fragment of v_mfma_f32_16x16x32_bf16 (lane: row l&15, 8 consecutive k at 8*(l>>4)) is loaded
+// straight from HBM -- every weight byte is fetched once, 64 contiguous bytes per row per step -- the
+// activation fragment (lane: batch row l&15) comes from L2.  Partial sums of the 4 waves meet in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int NB, int EPI>
+__global__ __launch_bounds__(256) void decode_gemv_kernel(DecGemvArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_red[3][NT * NB][64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    const int n0 = blockIdx.x * 16 * NT;
+    const int K = a.K, nsteps = K / 32;
+    f32x4 acc[NT][NB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wp[t] = a.W + (long)(n0 + t * 16 + fr) * K + fc * 8;
+    const bf16_t* xp[NB];
+    bool xv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        xv[b] = b * 16 + fr < a.B;
+        xp[b] = a.X + (long)(xv[b] ? b * 16 + fr : 0) * K + fc * 8;
+    }
+    constexpr int UNR = 4;
+    int s = wave;
+    for (; s + 4 * (UNR - 1) < nsteps; s += 4 * UNR) {
+        uint4 wf[UNR][NT], xf[UNR][NB];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int k = (s + 4 * u) * 32;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[u][t] = *reinterpret_cast<const uint4*>(wp[t] + k);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) xf[u][b] = xv[b] ? *reinterpret_cast<const uint4*>(xp[b] + k) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wf[u][t]),
+                                                                        __builtin_bit_cast(mfma_bf16x8, xf[u][b]), acc[t][b], 0, 0, 0);
+    }
+    for (; s < nsteps; s += 4) {
+        const int k = s * 32;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint4 wf = *reinterpret_cast<const uint4*>(wp[t] + k);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint4 xf = xv[b] ? *reinterpret_cast<const uint4*>(xp[b] + k) : make_uint4(0, 0, 0, 0);
+                acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, wf),
+                                                                    __builtin_bit_cast(mfma_bf16x8, xf), acc[t][b], 0, 0, 0);
+            }
+        }
+    }
+    // cross-wave reduction in a fixed order (wave 0 + 1 + 2 + 3): deterministic
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                *reinterpret_cast<f32x4*>(&s_red[wave - 1][t * NB + b][lane * 4]) = acc[t][b];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                f32x4 r = *reinterpret_cast<const f32x4*>(&s_red[w][t * NB + b][lane * 4]);
+                acc[t][b] += r;
+            }
+    // accumulator layout: acc[t][b][j] = out[batch b*16 + fr][n0 + t*16 + fc*4 + j]
+    if (EPI == DEC_EPI_BF16 || EPI == DEC_EPI_RESID) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = b * 16 + fr;
+                if (row < a.B) {
+                    bf16_t* p = a.out + (long)row * a.N + n0 + t * 16 + fc * 4;
+                    float4 v = make_float4(acc[t][b][0], acc[t][b][1], acc[t][b][2], acc[t][b][3]);
+                    if (EPI == DEC_EPI_RESID) {
+                        float4 r = load_bf16x4(p);
+                        v.x = r.x + bf16_round(v.x); v.y = r.y + bf16_round(v.y);
+                        v.z = r.z + bf16_round(v.z); v.w = r.w + bf16_round(v.w);
+                    }
+                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
+                }
+            }
+    } else if (EPI == DEC_EPI_SWIGLU) {
+        // rows come in blocks of 32: 16 gate rows then the 16 matching up rows -> tile pairs (2i, 2i+1)
+#pragma unroll
+        for (int t = 0; t + 1 < NT; t += 2)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = b * 16 + fr;
+                if (row < a.B) {
+                    float4 v;
+                    v.x = swiglu_bf16(acc[t][b][0], acc[t + 1][b][0]);
+                    v.y = swiglu_bf16(acc[t][b][1], acc[t + 1][b][1]);
+                    v.z = swiglu_bf16(acc[t][b][2], acc[t + 1][b][2]);
+                    v.w = swiglu_bf16(acc[t][b][3], acc[t + 1][b][3]);
+                    bf16_t* p = a.out + (long)row * (a.N / 2) + (n0 + t * 16) / 2 + fc * 4;
+                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
+                }
+            }
+    } else {   // DEC_EPI_LOGITS: bf16-rounded logits, per-block argmax with lowest-index ties
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int row = b * 16 + fr;
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + t * 16 + fc * 4 + j;
+                    const float v = bf16_round(acc[t][b][j]);
+                    if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
+                    if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+                }
+#pragma unroll
+            for (int ofs = 16; ofs < 64; ofs <<= 1) {
+                float ov = __shfl_xor(best, ofs, 64);
+                int oi = __shfl_xor(bidx, ofs, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (fc == 0 && row < a.B) {
+                a.part_val[(long)row * gridDim.x + blockIdx.x] = best;
+                a.part_idx[(long)row * gridDim.x + blockIdx.x] = bidx;
+            }
+        }
+    }
+}
+
+static int dec_nt(DecEpi epi, int N) {
+    if (epi == DEC_EPI_LOGITS) return N % 64 == 0 ? 4 : (N % 32 == 0 ? 2 : 1);
+    if (epi == DEC_EPI_SWIGLU) return 2;
+    return 1;
+}
+
+int decode_gemv_blocks(DecEpi epi, int N) { return N / (16 * dec_nt(epi, N)); }
+
+template <int NT, int EPI>
+static void dec_launch_nb(const DecGemvArgs& a, int blocks, hipStream_t s) {
+    const int nb = (a.B + 15) / 16;
+    switch (nb) {
+        case 1: hipLaunchKernelGGL((decode_gemv_kernel<NT, 1, EPI>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((decode_gemv_kernel<NT, 2, EPI>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((decode_gemv_kernel<NT, 3, EPI>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((decode_gemv_kernel<NT, 4, EPI>), dim3(blocks), dim3(256), 0, s, a); break;
+        default: throw std::length_error("decode batch > 64 rows");
+    }
+}
+
+int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s) {
+    if (a.B <= 0) return 0;
+    if (a.K % 32 != 0) throw std::invalid_argument("decode gemv: K must be a multiple of 32");
+    const int nt = dec_nt(epi, a.N);
+    if (a.N % (16 * nt) != 0) throw std::invalid_argument("decode gemv: N not a multiple of the row tile");
+    const int blocks = a.N / (16 * nt);
+    switch (epi) {
+        case DEC_EPI_BF16: dec_launch_nb<1, DEC_EPI_BF16>(a, blocks, s); break;
+        case DEC_EPI_RESID: dec_launch_nb<1, DEC_EPI_RESID>(a, blocks, s); break;
+        case DEC_EPI_SWIGLU: dec_launch_nb<2, DEC_EPI_SWIGLU>(a, blocks, s); break;
+        case DEC_EPI_LOGITS:
+            if (nt == 4) dec_launch_nb<4, DEC_EPI_LOGITS>(a, blocks, s);
+            else if (nt == 2) dec_launch_nb<2, DEC_EPI_LOGITS>(a, blocks, s);
+            else dec_launch_nb<1, DEC_EPI_LOGITS>(a, blocks, s);
+            break;
+    }
+    return blocks;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode attention: one workgroup per (kv head, batch row), 8 waves.  Phase 1: waves 0..rep-1 norm +
+// rope their query head, wave rep does the new key, wave rep+1 copies the new value; K/V are appended
+// to the cache.  Phase 2: waves stream the cached keys/values -- a wave instruction covers 64/CPR
+// consecutive rows (CPR = hd/8 chunks of 16 bytes per row, i.e. 1 KiB contiguous for hd = 128) --
+// every lane keeps an online-softmax state for the rows of its slot and its 8 head dims; the states
+// are merged across slots (shuffles) and waves (LDS) at the end.  Softmax stays in f32.
+// ------------------------------------------------------------------------------------------------
+constexpr int DA_WAVES = 8;
+constexpr int DA_MAXREP = 4;
+
+template <int HD, int REP>
+__global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
+    const bf16_t* __restrict__ qkv, const int* __restrict__ ctx_len, int heads, int kv_heads,
+    const bf16_t* __restrict__ qn_w, const bf16_t* __restrict__ kn_w, float eps, const float* __restrict__ rope_cos,
+    const float* __restrict__ rope_sin, KVLayout cache, bf16_t* __restrict__ out, float scale) {
+    constexpr int CPR = HD / 8, KPI = 64 / CPR, HALF = HD / 2;
+    __shared__ float s_q[REP][HD];
+    __shared__ float s_kn[HD];
+    __shared__ float s_vn[HD];
+    __shared__ float s_m[DA_WAVES][REP], s_l[DA_WAVES][REP];
+    __shared__ float s_o[DA_WAVES][REP][HD];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = ctx_len[b];
+    const int nh = heads + 2 * kv_heads;
+    const bf16_t* row = qkv + (long)b * nh * HD;
+    // ---- phase 1 -------------------------------------------------------------------------------
+    if (wave <= REP) {
+        const bool isq = wave < REP;
+        const bf16_t* src = row + (long)(isq ? kvh * REP + wave : heads + kvh) * HD;
+        const bool act = lane < HALF;
+        float x1 = act ? bf16_to_f32(src[lane]) : 0.0f, x2 = act ? bf16_to_f32(src[lane + HALF]) : 0.0f;
+        const float inv = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)HD + eps);
+        if (act) {
+            const bf16_t* nw = isq ? qn_w : kn_w;
+            float o1, o2;
+            norm_rope_pair(x1, x2, bf16_to_f32(nw[lane]), bf16_to_f32(nw[lane + HALF]), inv,
+                           rope_cos[(long)pos * HALF + lane], rope_sin[(long)pos * HALF + lane], o1, o2);
+            if (isq) {
+                s_q[wave][lane] = o1;
+                s_q[wave][lane + HALF] = o2;
+            } else {
+                s_kn[lane] = o1;
+                s_kn[lane + HALF] = o2;
+                bf16_t* dk = cache.k + cache.off(b, kvh, pos);
+                dk[lane] = f32_to_bf16(o1);
+                dk[lane + HALF] = f32_to_bf16(o2);
+            }
+        }
+    } else if (wave == REP + 1) {
+        const bf16_t* src = row + (long)(heads + kv_heads + kvh) * HD;
+        bf16_t* dv = cache.v + cache.off(b, kvh, pos);
+        for (int i = lane; i < HD; i += 64) {
+            bf16_t v = src[i];
+            s_vn[i] = bf16_to_f32(v);
+            dv[i] = v;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: cached rows [0, pos) from HBM, the new row from LDS ----------------------------------
+    const int c = lane % CPR, slot = lane / CPR;
+    float q[REP][8];
+#pragma unroll
+    for (int r = 0; r < REP; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[r][j] = s_q[r][c * 8 + j];
+    float m[REP], l[REP], o[REP][8];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        m[r] = -INFINITY;
+        l[r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[r][j] = 0.0f;
+    }
+    const bf16_t* kb = cache.k + cache.off(b, kvh, 0) + c * 8;
+    const bf16_t* vb = cache.v + cache.off(b, kvh, 0) + c * 8;
+    auto absorb = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = fmaf(q[r][j], kf[j], d);
+#pragma unroll
+            for (int ofs = 1; ofs < CPR; ofs <<= 1) d += __shfl_xor(d, ofs, 64);
+            const float sc = valid ? d * scale : -INFINITY;
+            const float m_new = fmaxf(m[r], sc);
+            const float m_ref = m_new == -INFINITY ? 0.0f : m_new;
+            const float alpha = expf(m[r] - m_ref), p = expf(sc - m_ref);
+            l[r] = l[r] * alpha + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[r][j] = fmaf(p, vf[j], o[r][j] * alpha);
+            m[r] = m_new;
+        }
+    };
+    const int ngroups = (pos + KPI - 1) / KPI;
+    for (int g = wave; g < ngroups; g += DA_WAVES) {
+        const int key = g * KPI + slot;
+        const bool valid = key < pos;
+        uint4 ku = make_uint4(0, 0, 0, 0), vu = make_uint4(0, 0, 0, 0);
+        if (valid) {
+            ku = *reinterpret_cast<const uint4*>(kb + (long)key * HD);
+            vu = *reinterpret_cast<const uint4*>(vb + (long)key * HD);
+        }
+        float kf[8], vf[8];
+        const bf16_t* ke = reinterpret_cast<const bf16_t*>(&ku);
+        const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vu);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kf[j] = bf16_to_f32(ke[j]); vf[j] = bf16_to_f32(ve[j]); }
+        absorb(kf, vf, valid);
+    }
+    if (wave == DA_WAVES - 1) {      // the token's own key/value (slot 0 lanes only)
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kf[j] = s_kn[c * 8 + j]; vf[j] = s_vn[c * 8 + j]; }
+        absorb(kf, vf, slot == 0);
+    }
+    // merge the KPI slots of this wave (lanes with equal c)
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int ofs = CPR; ofs < 64; ofs <<= 1) {
+            const float mo = __shfl_xor(m[r], ofs, 64), lo = __shfl_xor(l[r], ofs, 64);
+            const float m_new = fmaxf(m[r], mo);
+            const float m_ref = m_new == -INFINITY ? 0.0f : m_new;
+            const float a0 = expf(m[r] - m_ref), a1 = expf(mo - m_ref);
+            l[r] = l[r] * a0 + lo * a1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float oo = __shfl_xor(o[r][j], ofs, 64);
+                o[r][j] = o[r][j] * a0 + oo * a1;
+            }
+            m[r] = m_new;
+        }
+        if (slot == 0) {
+            if (c == 0) { s_m[wave][r] = m[r]; s_l[wave][r] = l[r]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_o[wave][r][c * 8 + j] = o[r][j];
+        }
+    }
+    __syncthreads();
+    // merge waves: thread t < REP*HD owns one output element
+    for (int i = tid; i < REP * HD; i += DA_WAVES * 64) {
+        const int r = i / HD, d = i - r * HD;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < DA_WAVES; ++w) mm = fmaxf(mm, s_m[w][r]);
+        float num = 0.0f, den = 0.0f;
+#pragma unroll
+        for (int w = 0; w < DA_WAVES; ++w) {
+            const float a = s_m[w][r] == -INFINITY ? 0.0f : expf(s_m[w][r] - mm);
+            num += s_o[w][r][d] * a;
+            den += s_l[w][r] * a;
+        }
+        out[(long)b * heads * HD + (long)(kvh * REP + r) * HD + d] = f32_to_bf16(num / den);
+    }
+}
+
+void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int heads, int kv_heads, int hd,
+                             const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
+                             const float* rope_sin, KVLayout cache, bf16_t* out, hipStream_t s) {
+    if (B <= 0) return;
+    const int rep = heads / kv_heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    dim3 grid(kv_heads, B), block(DA_WAVES * 64);
+    if (hd == 128 && rep == 2)
+        hipLaunchKernelGGL((decode_attention_kernel<128, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
+                           eps, rope_cos, rope_sin, cache, out, scale);
+    else if (hd == 32 && rep == 2)
+        hipLaunchKernelGGL((decode_attention_kernel<32, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
+                           eps, rope_cos, rope_sin, cache, out, scale);
+    else
+        throw std::invalid_argument("decode attention: unsupported (head_dim, heads/kv_heads)");
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy bookkeeping + next-token embedding gather: one workgroup per batch row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __restrict__ part_val,
+                                                              const int* __restrict__ part_idx, int n_parts,
+                                                              GreedyState st, int advance_ctx,
+                                                              const bf16_t* __restrict__ embed, bf16_t* __restrict__ x, int H) {
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = tid; i < n_parts; i += 256) {
+        const float v = part_val[(long)b * n_parts + i];
+        const int n = part_idx[(long)b * n_parts + i];
+        if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+    }
+    s_v[tid] = best;
+    s_i[tid] = bidx;
+    __syncthreads();
+    for (int ofs = 128; ofs > 0; ofs >>= 1) {
+        if (tid < ofs) {
+            const float ov = s_v[tid + ofs];
+            const int oi = s_i[tid + ofs];
+            if (ov > s_v[tid] || (ov == s_v[tid] && oi < s_i[tid])) { s_v[tid] = ov; s_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    const int tok = s_i[0];
+    if (tid == 0) {
+        if (advance_ctx) st.ctx_len[b] += 1;
+        if (!st.finished[b]) {
+            const int n = st.lens[b];
+            st.tokens[(long)b * (st.max_new + 1) + n] = tok;
+            st.lens[b] = n + 1;
+            if ((tok == st.eos && !st.ignore_eos) || n + 1 >= st.max_tokens) {
+                st.finished[b] = 1;
+                atomicSub(st.n_active, 1);
+            }
+        }
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(embed + (long)tok * H);
+    uint4* dst = reinterpret_cast<uint4*>(x + (long)b * H);
+    for (int i = tid; i < H / 8; i += 256) dst[i] = src[i];
+}
+
+void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
+                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(greedy_finalize_kernel, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, st, advance_ctx,
+                       embed, x, H);
+}
+
+}  // namespace qasr

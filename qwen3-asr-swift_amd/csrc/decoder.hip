@@ -1,0 +1,461 @@
+// decoder.hip -- text decoder orchestration: prompt build + splice, prompt pass (packed, varlen),
+// greedy decode loop with a hipGraph-captured step, batch pipeline and stage entry points.
+//
+// Reference: Sources/Qwen3ASR/Qwen3ASR.swift:173-294 (generateText), :317-390 (greedy loop),
+// QuantizedTextDecoder.swift / FloatTextDecoder.swift (model), PreQuantizedEmbedding.swift:35-49.
+//
+// HBM layout (per engine):
+//   KV cache   bf16 [layer] x { K, V } [slot][kv_head][max_ctx][head_dim]   static, appended in place
+//   V^T        bf16 [slot][kv_head][head_dim][vt_stride]                    prompt pass only (one layer live)
+//   prompt pass activations are packed over all clips: row p = cu[clip] + position
+//   decode activations are [batch row][features]
+#include "engine.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace qasr {
+
+__global__ void interleave_gate_up_kernel(const bf16_t* __restrict__ gate, const bf16_t* __restrict__ up,
+                                          bf16_t* __restrict__ dst, int inter, int H) {
+    // dst rows in blocks of 32: 16 gate rows j0..j0+15 then the 16 up rows j0..j0+15
+    const int r = blockIdx.x;                      // 0 .. 2*inter-1
+    const int blk = r >> 5, w = r & 31;
+    const bf16_t* src = (w < 16 ? gate : up) + (long)(blk * 16 + (w & 15)) * H;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst + (long)r * H);
+    for (int i = threadIdx.x; i < H / 8; i += blockDim.x) d4[i] = s4[i];
+}
+
+__global__ void narrow_f32_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f32_to_bf16(src[i]);
+}
+
+__global__ void add_scalar_kernel(int* p, int n, int v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+
+void Engine::finalize_decoder() {
+    const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nkv = cfg_.kv_heads * hd, I = cfg_.inter;
+    if (cfg_.inter % 16 != 0 || H % 32 != 0) throw std::invalid_argument("decoder widths must be multiples of 16/32");
+    decw_.embed = wptr("model.embed_tokens.weight", {cfg_.vocab, H});
+    decw_.norm = wptr("model.norm.weight", {H});
+    decw_.layers.clear();
+    for (int i = 0; i < cfg_.dec_layers; ++i) {
+        const std::string p = "model.layers." + std::to_string(i) + ".";
+        DecLayerW L;
+        L.ln1 = wptr(p + "input_layernorm.weight", {H});
+        L.ln2 = wptr(p + "post_attention_layernorm.weight", {H});
+        L.qn = wptr(p + "self_attn.q_norm.weight", {hd});
+        L.kn = wptr(p + "self_attn.k_norm.weight", {hd});
+        L.wo = wptr(p + "self_attn.o_proj.weight", {H, nq});
+        L.wdown = wptr(p + "mlp.down_proj.weight", {H, I});
+        const bf16_t* wq = wptr(p + "self_attn.q_proj.weight", {nq, H});
+        const bf16_t* wk = wptr(p + "self_attn.k_proj.weight", {nkv, H});
+        const bf16_t* wv = wptr(p + "self_attn.v_proj.weight", {nkv, H});
+        auto qkv = std::make_unique<DevBuf>();
+        qkv->alloc((size_t)(nq + 2 * nkv) * H * sizeof(bf16_t));
+        QASR_HIP(hipMemcpyAsync(qkv->as<bf16_t>(), wq, (size_t)nq * H * 2, hipMemcpyDeviceToDevice, stream_));
+        QASR_HIP(hipMemcpyAsync(qkv->as<bf16_t>() + (size_t)nq * H, wk, (size_t)nkv * H * 2, hipMemcpyDeviceToDevice, stream_));
+        QASR_HIP(hipMemcpyAsync(qkv->as<bf16_t>() + (size_t)(nq + nkv) * H, wv, (size_t)nkv * H * 2, hipMemcpyDeviceToDevice, stream_));
+        L.wqkv = qkv->as<bf16_t>();
+        fused_.push_back(std::move(qkv));
+        const bf16_t* wg = wptr(p + "mlp.gate_proj.weight", {I, H});
+        const bf16_t* wu = wptr(p + "mlp.up_proj.weight", {I, H});
+        auto gu = std::make_unique<DevBuf>();
+        gu->alloc((size_t)2 * I * H * sizeof(bf16_t));
+        hipLaunchKernelGGL(interleave_gate_up_kernel, dim3(2 * I), dim3(128), 0, stream_, wg, wu, gu->as<bf16_t>(), I, H);
+        L.wgu = gu->as<bf16_t>();
+        fused_.push_back(std::move(gu));
+        decw_.layers.push_back(L);
+    }
+    // capacity: prompt = 16 fixed ids + audio tokens + context/language extras (Qwen3ASR.swift:199-233)
+    const int max_audio_tok = num_audio_tokens(mel_num_frames(max_samples_));
+    max_prompt_ = 16 + max_audio_tok + cfg_.max_prompt_extra;
+    max_ctx_ = ((max_prompt_ + cfg_.max_new_tokens + 63) / 64) * 64;
+    vt_stride_ = ((max_prompt_ + 63) / 64) * 64;
+    max_pos_ = cfg_.max_batch * max_prompt_;
+    // RoPE tables: theta_i = base^(-i/half), f32 like MLXNN.RoPE(traditional: false)
+    {
+        const int half = hd / 2;
+        std::vector<float> c((size_t)max_ctx_ * half), sn((size_t)max_ctx_ * half);
+        const float k = (float)(-std::log((double)cfg_.rope_theta) / (double)half);
+        for (int i = 0; i < half; ++i) {
+            const float inv = expf((float)i * k);
+            for (int p = 0; p < max_ctx_; ++p) {
+                const float ang = (float)p * inv;
+                c[(size_t)p * half + i] = cosf(ang);
+                sn[(size_t)p * half + i] = sinf(ang);
+            }
+        }
+        d_rope_cos_.alloc(c.size() * sizeof(float));
+        d_rope_sin_.alloc(sn.size() * sizeof(float));
+        QASR_HIP(hipMemcpyAsync(d_rope_cos_.p, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+        QASR_HIP(hipMemcpyAsync(d_rope_sin_.p, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+        QASR_HIP(hipStreamSynchronize(stream_));
+    }
+    const int B = cfg_.max_batch, nh = cfg_.heads + 2 * cfg_.kv_heads;
+    kcache_.clear();
+    vcache_.clear();
+    const size_t cache_bytes = (size_t)B * cfg_.kv_heads * max_ctx_ * hd * sizeof(bf16_t);
+    for (int i = 0; i < cfg_.dec_layers; ++i) {
+        kcache_.push_back(std::make_unique<DevBuf>());
+        vcache_.push_back(std::make_unique<DevBuf>());
+        kcache_.back()->alloc(cache_bytes);
+        vcache_.back()->alloc(cache_bytes);
+    }
+    d_vt_.alloc((size_t)B * cfg_.kv_heads * hd * vt_stride_ * sizeof(bf16_t));
+    QASR_HIP(hipMemsetAsync(d_vt_.p, 0, d_vt_.bytes, stream_));   // masked keys multiply stale bytes by P = 0
+    d_px_.alloc((size_t)max_pos_ * H * 2);
+    d_ph_.alloc((size_t)max_pos_ * H * 2);
+    d_pqkv_.alloc((size_t)max_pos_ * nh * hd * 2);
+    d_pqr_.alloc((size_t)max_pos_ * nq * 2);
+    d_pattn_.alloc((size_t)max_pos_ * nq * 2);
+    d_pact_.alloc((size_t)max_pos_ * I * 2);
+    d_dx_.alloc((size_t)B * H * 2);
+    d_dh_.alloc((size_t)B * H * 2);
+    d_dqkv_.alloc((size_t)B * nh * hd * 2);
+    d_dattn_.alloc((size_t)B * nq * 2);
+    d_dact_.alloc((size_t)B * I * 2);
+    d_logits_.alloc((size_t)B * cfg_.vocab * sizeof(float));
+    n_parts_ = decode_gemv_blocks(DEC_EPI_LOGITS, cfg_.vocab);
+    d_part_val_.alloc((size_t)B * n_parts_ * sizeof(float));
+    d_part_idx_.alloc((size_t)B * n_parts_ * sizeof(int));
+    const size_t pmeta = (size_t)max_pos_ * 4 * sizeof(int) + (size_t)(3 * B + 2) * sizeof(int);
+    h_pmeta_.alloc(pmeta);
+    d_pmeta_.alloc(pmeta);
+    // greedy state: tokens [B][max_new+1] | lens [B] | finished [B] | ctx_len [B] | n_active [1]
+    const size_t gs = ((size_t)B * (cfg_.max_new_tokens + 1) + 3 * B + 4) * sizeof(int);
+    d_gstate_.alloc(gs);
+    int* g = d_gstate_.as<int>();
+    gstate_.tokens = g;
+    gstate_.lens = g + (size_t)B * (cfg_.max_new_tokens + 1);
+    gstate_.finished = gstate_.lens + B;
+    gstate_.ctx_len = gstate_.finished + B;
+    gstate_.n_active = gstate_.ctx_len + B;
+    gstate_.max_new = cfg_.max_new_tokens;
+    gstate_.eos = cfg_.tok_im_end;
+    for (auto& e : ev_)
+        if (!e) QASR_HIP(hipEventCreate(&e));
+    QASR_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- prompt planning (integer work, R7) ----------------------------------------------------------
+void Engine::plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio) {
+    const int B = (int)n_audio.size();
+    const int n_ctx = opt && opt->context_ids ? opt->n_context : 0;
+    const int n_lang = opt && opt->language_ids ? opt->n_language : 0;
+    if (n_ctx + n_lang > cfg_.max_prompt_extra) throw std::length_error("context + language ids exceed max_prompt_extra");
+    char* hp = h_pmeta_.as<char>();
+    int* ids = reinterpret_cast<int*>(hp);
+    int* asrc = ids + max_pos_;
+    int* slot = asrc + max_pos_;
+    int* pos = slot + max_pos_;
+    int* cu = pos + max_pos_;
+    int* slotclip = cu + (B + 1);
+    int* last = slotclip + B;
+    int p = 0;
+    max_len_ = 0;
+    prompt_len_.assign(B, 0);
+    cu[0] = 0;
+    for (int b = 0; b < B; ++b) {
+        const int start = p;
+        auto push = [&](int id, int a) { ids[p] = id; asrc[p] = a; slot[p] = b; pos[p] = p - start; ++p; };
+        // Qwen3ASR.swift:199-233
+        push(cfg_.tok_im_start, -1); push(cfg_.tok_system, -1); push(cfg_.tok_newline, -1);
+        for (int i = 0; i < n_ctx; ++i) push(opt->context_ids[i], -1);
+        push(cfg_.tok_im_end, -1); push(cfg_.tok_newline, -1);
+        push(cfg_.tok_im_start, -1); push(cfg_.tok_user, -1); push(cfg_.tok_newline, -1); push(cfg_.tok_audio_start, -1);
+        for (int i = 0; i < n_audio[b]; ++i) push(cfg_.tok_audio_pad, clip_tok_off_[b] + i);
+        push(cfg_.tok_audio_end, -1); push(cfg_.tok_im_end, -1); push(cfg_.tok_newline, -1);
+        push(cfg_.tok_im_start, -1); push(cfg_.tok_assistant, -1); push(cfg_.tok_newline, -1);
+        for (int i = 0; i < n_lang; ++i) push(opt->language_ids[i], -1);
+        push(cfg_.tok_asr_text, -1);
+        prompt_len_[b] = p - start;
+        if (prompt_len_[b] > max_prompt_) throw std::length_error("prompt longer than engine capacity");
+        max_len_ = std::max(max_len_, prompt_len_[b]);
+        cu[b + 1] = p;
+        slotclip[b] = b;
+        last[b] = p - 1;
+    }
+    n_pos_ = p;
+    // one upload: the five per-position arrays are not contiguous (max_pos_ stride) -> copy whole block
+    const size_t bytes = (size_t)max_pos_ * 4 * sizeof(int) + (size_t)(3 * B + 1) * sizeof(int);
+    QASR_HIP(hipMemcpyAsync(d_pmeta_.p, h_pmeta_.p, bytes, hipMemcpyHostToDevice, stream_));
+    int* dp = d_pmeta_.as<int>();
+    d_p_ids_ = dp;
+    d_p_audio_src_ = dp + max_pos_;
+    d_p_slot_ = dp + 2 * (size_t)max_pos_;
+    d_p_pos_ = dp + 3 * (size_t)max_pos_;
+    d_p_cu_ = dp + 4 * (size_t)max_pos_;
+    d_p_slotclip_ = d_p_cu_ + (B + 1);
+    d_p_last_ = d_p_slotclip_ + B;
+    h_ctx0_ = prompt_len_;
+}
+
+void Engine::reset_greedy_state(int max_tokens, bool ignore_eos) {
+    const int B = batch_;
+    cur_max_tokens_ = max_tokens;
+    cur_ignore_eos_ = ignore_eos;
+    gstate_.max_tokens = max_tokens;
+    gstate_.ignore_eos = ignore_eos ? 1 : 0;
+    // tokens = -1, lens = finished = 0, ctx_len = prompt_len, n_active = B
+    QASR_HIP(hipMemsetAsync(gstate_.tokens, 0xff, (size_t)cfg_.max_batch * (cfg_.max_new_tokens + 1) * sizeof(int), stream_));
+    QASR_HIP(hipMemsetAsync(gstate_.lens, 0, (size_t)2 * cfg_.max_batch * sizeof(int), stream_));
+    std::vector<int> init(cfg_.max_batch + 1, 0);
+    for (int b = 0; b < B; ++b) init[b] = h_ctx0_[b];
+    // ctx_len [max_batch] then n_active: two small copies from pageable memory are synchronous wrt host
+    QASR_HIP(hipMemcpyAsync(gstate_.ctx_len, init.data(), (size_t)cfg_.max_batch * sizeof(int), hipMemcpyHostToDevice, stream_));
+    int nact = B;
+    QASR_HIP(hipMemcpyAsync(gstate_.n_active, &nact, sizeof(int), hipMemcpyHostToDevice, stream_));
+    QASR_HIP(hipStreamSynchronize(stream_));
+    steps_done_ = 0;
+}
+
+void Engine::run_lm_head(bool want_logits) {
+    const int H = cfg_.hidden;
+    rmsnorm_rows_launch(d_dx_.as<bf16_t>(), decw_.norm, d_dh_.as<bf16_t>(), batch_, H, cfg_.rms_eps, stream_);
+    DecGemvArgs a{};
+    a.W = decw_.embed; a.X = d_dh_.as<bf16_t>(); a.B = batch_; a.N = cfg_.vocab; a.K = H;
+    a.logits = want_logits ? d_logits_.as<float>() : nullptr;
+    a.part_val = d_part_val_.as<float>();
+    a.part_idx = d_part_idx_.as<int>();
+    decode_gemv_launch(DEC_EPI_LOGITS, a, stream_);
+}
+
+void Engine::run_prefill(bool want_logits) {
+    const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
+    hipStream_t s = stream_;
+    bf16_t *x = d_px_.as<bf16_t>(), *h = d_ph_.as<bf16_t>(), *qkv = d_pqkv_.as<bf16_t>(), *qr = d_pqr_.as<bf16_t>();
+    bf16_t *at = d_pattn_.as<bf16_t>(), *act = d_pact_.as<bf16_t>();
+    const int P = n_pos_;
+    embed_splice_launch(d_p_ids_, d_p_audio_src_, decw_.embed, d_audio_.as<bf16_t>(), x, P, H, s);
+    for (int l = 0; l < cfg_.dec_layers; ++l) {
+        const DecLayerW& L = decw_.layers[l];
+        KVLayout kv{kcache_[l]->as<bf16_t>(), vcache_[l]->as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd};
+        rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
+        gemm_nt(ADense{h, H, P, H}, L.wqkv, H, P, nh * hd, H, EpiBiasActBf16<0>{qkv, (long)nh * hd, nullptr}, s);
+        qk_norm_rope_launch(qkv, d_p_slot_, d_p_pos_, P, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
+                            d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), qr, kv, d_vt_.as<bf16_t>(), vt_stride_, s);
+        prefill_attention_launch(qr, kv, d_vt_.as<bf16_t>(), vt_stride_, d_p_cu_, d_p_slotclip_, batch_, max_len_,
+                                 cfg_.heads, at, s);
+        gemm_nt(ADense{at, nq, P, nq}, L.wo, nq, P, H, nq, EpiResidBf16{x, H}, s);
+        rmsnorm_rows_launch(x, L.ln2, h, P, H, cfg_.rms_eps, s);
+        gemm_nt_swiglu(ADense{h, H, P, H}, L.wgu, H, P, 2 * I, H, EpiBiasActBf16<0>{act, I, nullptr}, s);
+        gemm_nt(ADense{act, I, P, I}, L.wdown, I, P, H, I, EpiResidBf16{x, H}, s);
+    }
+    // last position of every clip -> decode rows (Qwen3ASR.swift:254-256)
+    gather_rows_launch(x, d_p_last_, d_dx_.as<bf16_t>(), batch_, H, s);
+    run_lm_head(want_logits);
+    QASR_HIP(hipGetLastError());
+}
+
+void Engine::run_decode_step(bool want_logits, bool greedy) {
+    const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
+    hipStream_t s = stream_;
+    bf16_t *x = d_dx_.as<bf16_t>(), *h = d_dh_.as<bf16_t>(), *qkv = d_dqkv_.as<bf16_t>(), *at = d_dattn_.as<bf16_t>();
+    bf16_t* act = d_dact_.as<bf16_t>();
+    const int B = batch_;
+    for (int l = 0; l < cfg_.dec_layers; ++l) {
+        const DecLayerW& L = decw_.layers[l];
+        KVLayout kv{kcache_[l]->as<bf16_t>(), vcache_[l]->as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd};
+        rmsnorm_rows_launch(x, L.ln1, h, B, H, cfg_.rms_eps, s);
+        DecGemvArgs a{};
+        a.W = L.wqkv; a.X = h; a.B = B; a.N = nh * hd; a.K = H; a.out = qkv;
+        decode_gemv_launch(DEC_EPI_BF16, a, s);
+        decode_attention_launch(qkv, gstate_.ctx_len, B, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
+                                d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv, at, s);
+        a.W = L.wo; a.X = at; a.N = H; a.K = nq; a.out = x;
+        decode_gemv_launch(DEC_EPI_RESID, a, s);
+        rmsnorm_rows_launch(x, L.ln2, h, B, H, cfg_.rms_eps, s);
+        a.W = L.wgu; a.X = h; a.N = 2 * I; a.K = H; a.out = act;
+        decode_gemv_launch(DEC_EPI_SWIGLU, a, s);
+        a.W = L.wdown; a.X = act; a.N = H; a.K = I; a.out = x;
+        decode_gemv_launch(DEC_EPI_RESID, a, s);
+    }
+    run_lm_head(want_logits);
+    if (greedy)
+        greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, B, 1, decw_.embed,
+                               d_dx_.as<bf16_t>(), H, s);
+}
+
+// Greedy loop (Qwen3ASR.swift:344-389): token 0 comes from the prompt pass; every further token costs
+// one decode step.  The step is captured once into a hipGraph (all per-step state -- ctx_len, tokens,
+// finished -- lives in HBM, so the kernel arguments never change) and replayed.  With natural EOS the
+// host polls n_active every 8 steps; with ignore_eos the loop is free of host synchronisation.
+void Engine::decode_loop() {
+    const int max_steps = cur_max_tokens_ - 1;
+    if (max_steps <= 0) return;
+    const long key = ((long)batch_ << 32) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
+    if (use_graph_ && (graph_exec_ == nullptr || graph_key_ != key)) {
+        if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+        hipGraph_t g = nullptr;
+        QASR_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        try {
+            run_decode_step(false, true);
+        } catch (...) {
+            (void)hipStreamEndCapture(stream_, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        QASR_HIP(hipStreamEndCapture(stream_, &g));
+        QASR_HIP(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
+        QASR_HIP(hipGraphDestroy(g));
+        graph_key_ = key;
+    }
+    int h_active = batch_;
+    for (int step = 0; step < max_steps; ++step) {
+        if (use_graph_) QASR_HIP(hipGraphLaunch(graph_exec_, stream_));
+        else run_decode_step(false, true);
+        ++steps_done_;
+        if (!cur_ignore_eos_ && (step % 8 == 7)) {
+            QASR_HIP(hipMemcpyAsync(&h_active, gstate_.n_active, sizeof(int), hipMemcpyDeviceToHost, stream_));
+            QASR_HIP(hipStreamSynchronize(stream_));
+            if (h_active <= 0) break;
+        }
+    }
+}
+
+// ---- batch pipeline --------------------------------------------------------------------------------
+void Engine::batch_begin(const float* const* pcm, const size_t* n, size_t B, const qasr_options* opt) {
+    if (!finalized_) throw std::runtime_error("weights not finalized");
+    if (B == 0) throw std::invalid_argument("empty batch");
+    int max_tokens = opt && opt->max_tokens > 0 ? opt->max_tokens : cfg_.max_new_tokens;
+    if (max_tokens > cfg_.max_new_tokens) throw std::length_error("max_tokens exceeds engine capacity");
+    upload_pcm(pcm, n, B);
+    plan_encoder();
+    std::vector<int> n_audio;
+    for (auto& c : clips_) n_audio.push_back(c.n_tokens);
+    plan_prefill(opt, n_audio);
+    reset_greedy_state(max_tokens, opt && opt->ignore_eos);
+    QASR_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::batch_run() {
+    hipStream_t s = stream_;
+    QASR_HIP(hipEventRecord(ev_[0], s));
+    run_mel();
+    QASR_HIP(hipEventRecord(ev_[1], s));
+    run_encoder();
+    QASR_HIP(hipEventRecord(ev_[2], s));
+    run_prefill(false);
+    greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, batch_, 0, decw_.embed,
+                           d_dx_.as<bf16_t>(), cfg_.hidden, s);
+    QASR_HIP(hipEventRecord(ev_[3], s));
+    decode_loop();
+    QASR_HIP(hipEventRecord(ev_[4], s));
+}
+
+void Engine::batch_sync() { QASR_HIP(hipStreamSynchronize(stream_)); }
+
+void Engine::batch_tokens(int32_t* tokens, int32_t* lens) {
+    const int stride = cfg_.max_new_tokens + 1;
+    QASR_HIP(hipMemcpyAsync(tokens, gstate_.tokens, (size_t)batch_ * stride * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    QASR_HIP(hipMemcpyAsync(lens, gstate_.lens, (size_t)batch_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    QASR_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::batch_timings(float ms[5], int32_t* n_steps) {
+    QASR_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < 4; ++i) QASR_HIP(hipEventElapsedTime(&ms[i], ev_[i], ev_[i + 1]));
+    QASR_HIP(hipEventElapsedTime(&ms[4], ev_[0], ev_[4]));
+    if (n_steps) *n_steps = steps_done_;
+}
+
+// Average duration of `reps` back-to-back launches of one decode-step kernel group on the engine
+// stream (HIP events on that stream), with the current batch's state.  Algorithmic bytes:
+//   0: weight-streaming GEMVs of ONE decoder layer (qkv + o + gate/up + down weights, bf16)
+//   1: decode attention of ONE layer (K + V rows of every batch row at its current ctx)
+//   2: LM head (vocab x hidden bf16)
+void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_launch) {
+    if (!finalized_ || batch_ <= 0) throw std::runtime_error("kernel_probe needs a prepared batch");
+    const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
+    const DecLayerW& L = decw_.layers[0];
+    KVLayout kv{kcache_[0]->as<bf16_t>(), vcache_[0]->as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd};
+    hipStream_t s = stream_;
+    std::vector<int> ctx(batch_);
+    QASR_HIP(hipMemcpy(ctx.data(), gstate_.ctx_len, batch_ * sizeof(int), hipMemcpyDeviceToHost));
+    auto body = [&]() {
+        DecGemvArgs a{};
+        a.B = batch_;
+        if (which == 0) {
+            a.W = L.wqkv; a.X = d_dh_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
+            decode_gemv_launch(DEC_EPI_BF16, a, s);
+            a.W = L.wo; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();
+            decode_gemv_launch(DEC_EPI_BF16, a, s);
+            a.W = L.wgu; a.X = d_dh_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
+            decode_gemv_launch(DEC_EPI_SWIGLU, a, s);
+            a.W = L.wdown; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
+            decode_gemv_launch(DEC_EPI_BF16, a, s);
+        } else if (which == 1) {
+            decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, batch_, cfg_.heads, cfg_.kv_heads, hd, L.qn,
+                                    L.kn, cfg_.rms_eps, d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv,
+                                    d_dattn_.as<bf16_t>(), s);
+        } else {
+            a.W = decw_.embed; a.X = d_dh_.as<bf16_t>(); a.N = cfg_.vocab; a.K = H;
+            a.part_val = d_part_val_.as<float>(); a.part_idx = d_part_idx_.as<int>();
+            decode_gemv_launch(DEC_EPI_LOGITS, a, s);
+        }
+    };
+    for (int i = 0; i < 3; ++i) body();
+    QASR_HIP(hipEventRecord(ev_[5], s));
+    hipEvent_t e1;
+    QASR_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < reps; ++i) body();
+    QASR_HIP(hipEventRecord(e1, s));
+    QASR_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    QASR_HIP(hipEventElapsedTime(&ms, ev_[5], e1));
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)reps;
+    double bytes = 0;
+    if (which == 0) bytes = 2.0 * ((double)nh * hd * H + (double)H * nq + 2.0 * I * H + (double)H * I);
+    else if (which == 1) { for (int c : ctx) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)c; }
+    else bytes = 2.0 * (double)cfg_.vocab * H;
+    *bytes_per_launch = bytes;
+}
+
+// ---- stage entry points ------------------------------------------------------------------------------
+void Engine::prefill_logits_host(const float* audio_embeds, int n_audio, const qasr_options* opt, float* logits) {
+    if (!finalized_) throw std::runtime_error("weights not finalized");
+    if (n_audio < 0 || n_audio > max_tokens_) throw std::length_error("prefill: too many audio tokens");
+    batch_ = 1;
+    clips_.assign(1, ClipPlan{});
+    clips_[0].n_tokens = n_audio;
+    clip_tok_off_.assign(1, 0);
+    const long n = (long)n_audio * cfg_.hidden;
+    if (n > 0) {
+        float* stage = d_encx_.as<float>();   // f32 staging (capacity max_tokens * d_model >= n? checked below)
+        if ((size_t)n * sizeof(float) > d_encx_.bytes) throw std::length_error("prefill: staging too small");
+        QASR_HIP(hipMemcpyAsync(stage, audio_embeds, n * sizeof(float), hipMemcpyHostToDevice, stream_));
+        hipLaunchKernelGGL(narrow_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream_, stage, d_audio_.as<bf16_t>(), n);
+    }
+    plan_prefill(opt, std::vector<int>{n_audio});
+    reset_greedy_state(cfg_.max_new_tokens, true);
+    run_prefill(true);
+    QASR_HIP(hipMemcpyAsync(logits, d_logits_.p, (size_t)cfg_.vocab * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    QASR_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
+    if (!finalized_ || batch_ != 1) throw std::runtime_error("decode_forced needs a preceding prefill_logits");
+    HostBuf idx;
+    idx.alloc(sizeof(int));
+    DevBuf didx;
+    didx.alloc(sizeof(int));
+    for (int i = 0; i < n; ++i) {
+        if (tokens[i] < 0 || tokens[i] >= cfg_.vocab) throw std::invalid_argument("token id out of range");
+        *idx.as<int>() = tokens[i];
+        QASR_HIP(hipMemcpyAsync(didx.p, idx.p, sizeof(int), hipMemcpyHostToDevice, stream_));
+        gather_rows_launch(decw_.embed, didx.as<int>(), d_dx_.as<bf16_t>(), 1, cfg_.hidden, stream_);
+        run_decode_step(true, false);
+        hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(64), 0, stream_, gstate_.ctx_len, 1, 1);
+        QASR_HIP(hipMemcpyAsync(logits + (size_t)i * cfg_.vocab, d_logits_.p, (size_t)cfg_.vocab * sizeof(float),
+                                hipMemcpyDeviceToHost, stream_));
+        QASR_HIP(hipStreamSynchronize(stream_));
+    }
+}
+
+}  // namespace qasr

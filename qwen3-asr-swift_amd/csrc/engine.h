@@ -3,6 +3,7 @@
 #include "common.h"
 #include "mel.h"
 #include "enc_kernels.h"
+#include "dec_kernels.h"
 #include "qasr.h"
 #include <map>
 #include <memory>
@@ -89,6 +90,24 @@ public:
     void mel_host(const float* pcm, size_t n, float* out);
     void encode_host(const float* mel, int n_frames, float* out);
     int num_audio_tokens(int n_frames) const;
+    void prefill_logits_host(const float* audio_embeds, int n_audio, const qasr_options* opt, float* logits);
+    void decode_forced_host(const int32_t* tokens, int n, float* logits);
+
+    // batch pipeline (qasr_batch_*): H2D + plan | mel + encoder + prefill + greedy decode | D2H
+    void batch_begin(const float* const* pcm, const size_t* n, size_t B, const qasr_options* opt);
+    void batch_run();
+    void batch_sync();
+    void batch_tokens(int32_t* tokens, int32_t* lens);
+    void batch_timings(float ms[5], int32_t* n_steps);
+    void kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_launch);
+    int batch_size() const { return batch_; }
+
+    // tokenizer (R9)
+    void set_vocab(const int32_t* ids, const char* const* tokens, size_t n);
+    void load_vocab_files(const std::string& dir);
+    std::string detokenize(const int32_t* tokens, int n, bool strip_asr_prefix) const;
+    std::string result_text;              // owned result storage for qasr_transcribe / vtable
+    std::vector<int32_t> result_tokens;
 
     static ClipPlan plan_clip(const qasr_config& cfg, long n_samples, int extra_prompt);
 
@@ -101,6 +120,13 @@ private:
     void alloc_encoder_workspace();
     void plan_encoder();          // chunk / token / window tables of the current batch -> HBM
     void run_encoder();
+    void finalize_decoder();
+    void plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio);
+    void run_prefill(bool want_logits);
+    void run_decode_step(bool want_logits, bool greedy);
+    void run_lm_head(bool want_logits);
+    void reset_greedy_state(int max_tokens, bool ignore_eos);
+    void decode_loop();
 
     qasr_config cfg_;
     hipStream_t stream_ = nullptr;
@@ -143,6 +169,42 @@ private:
     int* d_cu_win_ = nullptr;
     int n_img_ = 0, n_tok_ = 0, n_win_ = 0;
     std::vector<int> clip_tok_off_;                // first packed audio token of each clip
+
+    // ---- text decoder ------------------------------------------------------------------------
+    struct DecLayerW {
+        const bf16_t *ln1, *wqkv, *qn, *kn, *wo, *ln2, *wgu, *wdown;
+    };
+    struct DecW {
+        const bf16_t *embed, *norm;
+        std::vector<DecLayerW> layers;
+    } decw_;
+    int max_prompt_ = 0, max_ctx_ = 0, max_pos_ = 0, vt_stride_ = 0;
+    DevBuf d_rope_cos_, d_rope_sin_;
+    std::vector<std::unique_ptr<DevBuf>> kcache_, vcache_;     // per layer
+    DevBuf d_vt_;
+    DevBuf d_px_, d_ph_, d_pqkv_, d_pqr_, d_pattn_, d_pact_;   // prefill (packed prompt positions)
+    DevBuf d_dx_, d_dh_, d_dqkv_, d_dattn_, d_dact_, d_logits_, d_part_val_, d_part_idx_;   // decode rows
+    HostBuf h_pmeta_;
+    DevBuf d_pmeta_;
+    int *d_p_ids_ = nullptr, *d_p_audio_src_ = nullptr, *d_p_slot_ = nullptr, *d_p_pos_ = nullptr;
+    int *d_p_cu_ = nullptr, *d_p_slotclip_ = nullptr, *d_p_last_ = nullptr;
+    int n_pos_ = 0, max_len_ = 0;
+    std::vector<int> prompt_len_;
+    DevBuf d_gstate_;                                          // tokens | lens | finished | ctx_len | n_active
+    GreedyState gstate_{};
+    int cur_max_tokens_ = 448;
+    bool cur_ignore_eos_ = false;
+    int n_parts_ = 0;
+    int steps_done_ = 0;
+    // decode-step graph, keyed by (B, max_tokens, ignore_eos)
+    hipGraphExec_t graph_exec_ = nullptr;
+    long graph_key_ = -1;
+    bool use_graph_ = true;
+    hipEvent_t ev_[6] = {};
+    std::vector<int> h_ctx0_;
+
+    // ---- tokenizer -----------------------------------------------------------------------------
+    std::unordered_map<int32_t, std::string> id_to_token_;
 };
 
 }  // namespace qasr

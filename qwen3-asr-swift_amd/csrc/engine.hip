@@ -57,6 +57,8 @@ Engine::Engine(const qasr_config& cfg) : cfg_(cfg) {
 
 Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     mel_tables_.release();
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -71,15 +73,18 @@ void Engine::set_tensor(const std::string& name, const void* host, int dtype, co
     finalized_ = false;
 }
 
-void Engine::load_directory(const std::string&) { throw std::runtime_error("safetensors loader not built yet"); }
 void Engine::finalize() {
     finalize_encoder();
+    finalize_decoder();
     finalized_ = true;
 }
 void Engine::unload() {
     QASR_HIP(hipStreamSynchronize(stream_));
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; graph_key_ = -1; }
     tensors_.clear();
     fused_.clear();
+    kcache_.clear();
+    vcache_.clear();
     finalized_ = false;
 }
 size_t Engine::memory_footprint() const {

@@ -84,9 +84,18 @@ struct AConv3x3s2 {
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
+__device__ __forceinline__ float gemm_swiglu(float g_acc, float u_acc) {
+    float g = bf16_round(g_acc), u = bf16_round(u_acc);
+    float sg = bf16_round(g * (1.0f / (1.0f + expf(-g))));
+    return bf16_round(sg * u);
+}
+
 __device__ __forceinline__ int gemm_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <class ALoad, class Epi>
+// MODE 0: epi(m, n, acc[n..n+3]).  MODE 1 (SwiGLU): weight rows come in blocks of 32 = 16 gate rows +
+// the 16 matching up rows; epi(m, j, act[j..j+3]) receives bf16(bf16(silu(bf16 g)) * bf16 u) for the
+// N/2 fused outputs (QuantizedTextDecoder.swift:132-137).
+template <class ALoad, class Epi, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw,
                                                                 int M, int N, int K, Epi epi) {
     __shared__ __attribute__((aligned(16))) char smem[2][2][GEMM_BM * 128];   // [buf][A|B][row*128B]
@@ -170,14 +179,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(ALoad aload, cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
-    const int er = lane >> 4, ec = (lane & 15) * 4;
+    if (MODE == 0) {
+        const int er = lane >> 4, ec = (lane & 15) * 4;
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        int row = it * 4 + er;
-        int m = m0 + wm * 64 + row, n = n0 + wn * 64 + ec;
-        if (m < M && n < N) {
-            float4 v = *reinterpret_cast<const float4*>(&ct[row * 64 + ec]);
-            epi(m, n, v);
+        for (int it = 0; it < 16; ++it) {
+            int row = it * 4 + er;
+            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + ec;
+            if (m < M && n < N) {
+                float4 v = *reinterpret_cast<const float4*>(&ct[row * 64 + ec]);
+                epi(m, n, v);
+            }
+        }
+    } else {
+        const int er = lane >> 3, e4 = (lane & 7) * 4, blk = e4 >> 4, e = e4 & 15;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            int row = it * 8 + er;
+            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + blk * 32;     // first gate row of the block
+            if (m < M && n < N) {
+                float4 g = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + e]);
+                float4 u = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + 16 + e]);
+                float4 v;
+                v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
+                v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
+                epi(m, n / 2 + e, v);
+            }
         }
     }
 }
@@ -186,7 +212,15 @@ template <class ALoad, class Epi>
 inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
+    hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
+}
+
+template <class ALoad, class Epi>
+inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    if (N % 32 != 0) throw std::invalid_argument("swiglu gemm: fused width must be a multiple of 32");
+    int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
 }
 
 // ------------------------------------------------------------------------------------------------

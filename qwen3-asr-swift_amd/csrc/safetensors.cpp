@@ -1,0 +1,157 @@
+// safetensors.cpp -- checkpoint directory loader (HF safetensors shards, reference key names).
+// Reference: Sources/Qwen3ASR/WeightLoading.swift:17-126,235-323, Sources/MLXCommon/WeightLoading.swift:48-165.
+//   audio_tower.*  float tensors (f32 / f16 / bf16 on disk)  -> bf16 in HBM
+//   model.*        either float Linear weights (FloatTextDecoder) or MLX affine-quantised triplets
+//                  {weight: uint32 [out, in*bits/32], scales, biases: [out, in/group]} which are
+//                  dequantised here as w = q*scale + bias (f32) and rounded to bf16 -- see DESIGN.md
+//                  (W4/W8 in-kernel dequant is the next scope row N1).
+#include "engine.h"
+#include "json.h"
+#include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include <cstring>
+
+namespace qasr {
+
+namespace {
+struct Mapped {
+    void* p = MAP_FAILED;
+    size_t n = 0;
+    int fd = -1;
+    explicit Mapped(const std::string& path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat " + path); }
+        n = (size_t)st.st_size;
+        p = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot mmap " + path); }
+    }
+    ~Mapped() {
+        if (p != MAP_FAILED) munmap(p, n);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+struct Entry {
+    std::string dtype;
+    std::vector<int64_t> shape;
+    const uint8_t* data;
+    size_t bytes;
+};
+
+float half_to_float(uint16_t h) {
+    uint32_t sign = (h & 0x8000u) << 16, exp = (h >> 10) & 0x1F, man = h & 0x3FF, out;
+    if (exp == 0) {
+        if (man == 0) out = sign;
+        else {
+            int e = -1;
+            do { ++e; man <<= 1; } while (!(man & 0x400));
+            out = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FF) << 13);
+        }
+    } else if (exp == 31) out = sign | 0x7F800000u | (man << 13);
+    else out = sign | ((exp + 112) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &out, 4);
+    return f;
+}
+
+float elem_f32(const Entry& e, size_t i) {
+    if (e.dtype == "F32") { float f; std::memcpy(&f, e.data + 4 * i, 4); return f; }
+    uint16_t h;
+    std::memcpy(&h, e.data + 2 * i, 2);
+    if (e.dtype == "BF16") return bf16_to_f32(h);
+    if (e.dtype == "F16") return half_to_float(h);
+    throw std::runtime_error("unsupported float dtype " + e.dtype);
+}
+}  // namespace
+
+void Engine::load_directory(const std::string& dir) {
+    std::vector<std::string> files;
+    if (DIR* d = opendir(dir.c_str())) {
+        while (dirent* de = readdir(d)) {
+            std::string f = de->d_name;
+            if (f.size() > 12 && f.compare(f.size() - 12, 12, ".safetensors") == 0) files.push_back(dir + "/" + f);
+        }
+        closedir(d);
+    } else throw std::runtime_error("cannot open model directory " + dir);
+    if (files.empty()) throw std::runtime_error("no .safetensors files in " + dir);
+    std::sort(files.begin(), files.end());
+    std::vector<std::unique_ptr<Mapped>> maps;
+    std::map<std::string, Entry> entries;
+    for (auto& f : files) {
+        maps.push_back(std::make_unique<Mapped>(f));
+        const uint8_t* base = (const uint8_t*)maps.back()->p;
+        const size_t n = maps.back()->n;
+        if (n < 8) throw std::runtime_error("truncated safetensors file " + f);
+        uint64_t hlen;
+        std::memcpy(&hlen, base, 8);
+        if (hlen > n - 8) throw std::runtime_error("bad safetensors header length in " + f);
+        Json h = JsonParser((const char*)base + 8, (size_t)hlen).parse();
+        const uint8_t* data = base + 8 + hlen;
+        const size_t data_n = n - 8 - (size_t)hlen;
+        for (auto& kv : h.obj) {
+            if (kv.first == "__metadata__") continue;
+            const Json *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
+            if (!dt || !sh || !off || off->arr.size() != 2) throw std::runtime_error("bad tensor entry " + kv.first);
+            Entry e;
+            e.dtype = dt->str;
+            for (auto& d : sh->arr) e.shape.push_back((int64_t)d.num);
+            size_t b = (size_t)off->arr[0].num, en = (size_t)off->arr[1].num;
+            if (b > en || en > data_n) throw std::runtime_error("tensor " + kv.first + " out of file bounds");
+            e.data = data + b;
+            e.bytes = en - b;
+            entries[kv.first] = e;
+        }
+    }
+    std::vector<bf16_t> tmp;
+    auto upload_float = [&](const std::string& name, const Entry& e) {
+        size_t numel = 1;
+        for (auto d : e.shape) numel *= (size_t)d;
+        size_t el = e.dtype == "F32" ? 4 : 2;
+        if (numel * el != e.bytes) throw std::runtime_error("tensor " + name + ": byte size does not match shape");
+        if (e.dtype == "BF16") { set_tensor(name, e.data, QASR_DTYPE_BF16, e.shape.data(), (int)e.shape.size()); return; }
+        tmp.resize(numel);
+        for (size_t i = 0; i < numel; ++i) tmp[i] = f32_to_bf16_host(elem_f32(e, i));
+        set_tensor(name, tmp.data(), QASR_DTYPE_BF16, e.shape.data(), (int)e.shape.size());
+    };
+    for (auto& kv : entries) {
+        const std::string& name = kv.first;
+        const bool audio = name.compare(0, 12, "audio_tower.") == 0, text = name.compare(0, 6, "model.") == 0;
+        if (!audio && !text) continue;
+        auto ends = [&](const char* s) { size_t l = strlen(s); return name.size() > l && name.compare(name.size() - l, l, s) == 0; };
+        if (ends(".scales") || ends(".biases")) continue;            // consumed with their .weight
+        const Entry& e = kv.second;
+        if (e.dtype == "U32" && ends(".weight")) {
+            const std::string stem = name.substr(0, name.size() - 7);
+            auto si = entries.find(stem + ".scales"), bi = entries.find(stem + ".biases");
+            if (si == entries.end() || bi == entries.end()) throw std::runtime_error("quantised " + name + " lacks scales/biases");
+            const int bits = cfg_.bits == 8 ? 8 : 4, per = 32 / bits, group = cfg_.group_size;
+            if (e.shape.size() != 2) throw std::runtime_error("quantised " + name + ": expected 2-D");
+            const int64_t out = e.shape[0], in = e.shape[1] * per;
+            if ((size_t)(out * e.shape[1] * 4) != e.bytes || si->second.shape != std::vector<int64_t>{out, in / group})
+                throw std::runtime_error("quantised " + name + ": shape mismatch (bits/group?)");
+            tmp.resize((size_t)out * in);
+            const uint32_t mask = (1u << bits) - 1u;
+            for (int64_t r = 0; r < out; ++r)
+                for (int64_t c = 0; c < in; ++c) {
+                    uint32_t wv;
+                    std::memcpy(&wv, e.data + 4 * (r * e.shape[1] + c / per), 4);
+                    const float q = (float)((wv >> (bits * (c % per))) & mask);      // LSB-first packing (mlx)
+                    const size_t g = (size_t)(r * (in / group) + c / group);
+                    tmp[(size_t)(r * in + c)] = f32_to_bf16_host(q * elem_f32(si->second, g) + elem_f32(bi->second, g));
+                }
+            int64_t shp[2] = {out, in};
+            set_tensor(name, tmp.data(), QASR_DTYPE_BF16, shp, 2);
+        } else {
+            upload_float(name, e);
+        }
+    }
+    load_vocab_files(dir);
+}
+
+}  // namespace qasr

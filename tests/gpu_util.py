@@ -55,6 +55,49 @@ class Engine:
         self.check(self.lib.qasr_encode(self.h, fptr(mel), mel.shape[1], fptr(out)))
         return out
 
+    def options(self, max_tokens=0, ignore_eos=False, context_ids=None, language_ids=None):
+        o = _lib.QasrOptions()
+        o.max_tokens, o.ignore_eos = max_tokens, int(ignore_eos)
+        self._keep = []
+        for name, ids in (("context", context_ids), ("language", language_ids)):
+            if ids:
+                arr = (C.c_int32 * len(ids))(*ids)
+                self._keep.append(arr)
+                setattr(o, name + "_ids", C.cast(arr, C.POINTER(C.c_int32)))
+                setattr(o, "n_" + name, len(ids))
+        return o
+
+    def prefill_logits(self, audio_embeds, **opt):
+        emb = np.ascontiguousarray(audio_embeds, dtype=np.float32)
+        logits = np.empty(self.cfg.vocab, dtype=np.float32)
+        o = self.options(**opt)
+        self.check(self.lib.qasr_prefill_logits(self.h, fptr(emb), emb.shape[0], C.byref(o), fptr(logits)))
+        return logits
+
+    def decode_forced(self, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        logits = np.empty((t.shape[0], self.cfg.vocab), dtype=np.float32)
+        self.check(self.lib.qasr_decode_forced(self.h, iptr(t), t.shape[0], fptr(logits)))
+        return logits
+
+    def transcribe_batch(self, clips, **opt):
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        B = len(clips)
+        ptrs = (C.POINTER(C.c_float) * B)(*[fptr(c) for c in clips])
+        ns = (C.c_size_t * B)(*[c.shape[0] for c in clips])
+        stride = self.cfg.max_new_tokens + 1
+        toks = np.full((B, stride), -7, dtype=np.int32)
+        lens = np.zeros(B, dtype=np.int32)
+        o = self.options(**opt)
+        self.check(self.lib.qasr_transcribe_batch(self.h, ptrs, ns, B, 16000, C.byref(o), iptr(toks), iptr(lens)))
+        return [toks[b, :lens[b]].tolist() for b in range(B)]
+
+    def timings(self):
+        ms = (C.c_float * 5)()
+        steps = C.c_int32()
+        self.check(self.lib.qasr_batch_timings(self.h, ms, C.byref(steps)))
+        return list(ms), steps.value
+
     def mel(self, pcm):
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         T = self.lib.qasr_num_mel_frames(pcm.shape[0])
