@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Qwen3-ASR transcribe() hot path on MI355X.
+
+Metric (BASELINE.json): audio-seconds / wall-second (RTF^-1), Qwen3-ASR-0.6B, 30 s @ 16 kHz clips,
+batch 32 per GPU (the metric's "b=32"; 8 GPUs x 32 = configs[2]'s 256 clips), bf16, synthetic
+waveforms + seeded random weights of the real architecture (no checkpoint / dataset offline).
+
+A "step" = one pass of the whole hot path (log-mel -> audio encoder -> prompt pass -> N_dec greedy
+decode steps -> token ids on host -> RCCL all_gather of the [B, 449] int32 token block) over one batch
+that is already resident in HBM (qasr_batch_begin uploads it before the timed region; the
+PCIe-inclusive rate is reported separately and never as `value`).  Decode length is forced to
+N_dec = 128 tokens per clip (EOS ignored) so the work is deterministic -- SURVEY.md section 8(d).
+
+Launch:  python bench.py [--gpus 1]            or, for N > 1 (one rank per GPU, RCCL):
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "qwen3-asr-swift_amd"))
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from qasr import _lib, synth          # noqa: E402
+from qasr.model import Qwen3ASRModel  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sd, pcm, n_dec):
+    """CPU restatement of the reference (oracle/, B=1 sequential like the Swift reference) timed on
+    this host's cores on ONE clip of the benchmark batch.  Checker code, used here only as the
+    reported baseline -- never on the product path."""
+    from oracle import config as OC, pipeline, precision as P
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))       # the GPU box grants a 16-core share per GPU
+    torch.set_num_threads(threads)
+    model = pipeline.OracleModel(sd, OC.AUDIO_SMALL, OC.TEXT_SMALL, OC.TOKENS, P.REFERENCE)
+    # bounded sample: the first third of one clip with a third of the forced tokens (cost is linear in
+    # clip length: 100-frame conv chunks, 104-token attention windows, prompt length 16 + 13/s)
+    frac = 3
+    pcm = pcm[: len(pcm) // frac]
+    n_dec = max(1, n_dec // frac)
+    model.W("model.embed_tokens.weight")   # materialise the f32 view of the tied head outside the timing
+    log(f"cpu_baseline: {threads} threads, {len(pcm) / 16000.0:.1f} s clip, {n_dec} tokens ...")
+    t0 = time.perf_counter()
+    toks = model.transcribe_tokens(pcm, max_tokens=n_dec, ignore_eos=True)
+    dt = time.perf_counter() - t0
+    assert len(toks) == n_dec
+    return {"value": round(len(pcm) / 16000.0 / dt, 3), "unit": "audio-seconds/sec", "cores": threads,
+            "kind": "port",
+            "sample": f"1/{frac} of one of the batch's clips ({len(pcm) / 16000.0:.0f} s, {n_dec} forced tokens), B=1 "
+                      f"sequential like the reference, fp32 torch-CPU restatement (not the Swift binary), "
+                      f"{dt:.1f} s of CPU work"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--decode-tokens", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, n_dec = args.batch, args.decode_tokens
+    log(f"rank {rank}/{world}: generating synthetic weights ...")
+    from qasr import config as QC
+    sd = synth.synth_state_dict(QC.AUDIO_SMALL, QC.TEXT_SMALL, seed=0, init="hf")
+    model = Qwen3ASRModel.from_state_dict(sd, preset="0.6B", device=local_rank, max_batch=B,
+                                          max_audio_seconds=int(np.ceil(args.seconds)), max_new_tokens=448)
+    # weak scaling: every rank gets its own B clips (clip ids rank*B ...), no data-path collective
+    clips = [synth.synth_waveform(rank * B + k, args.seconds) for k in range(B)]
+    stride = model.cfg.max_new_tokens + 1
+
+    log("weights resident; uploading batch ...")
+    t0 = time.perf_counter()
+    model.batch_begin(clips, max_tokens=n_dec, ignore_eos=True)
+    model.batch_sync()
+    h2d_s = time.perf_counter() - t0
+
+    gathered = torch.empty((world * B, stride), dtype=torch.int32, device="cuda")
+
+    def step():
+        model.batch_rewind()
+        model.batch_run()
+        toks, lens = model.batch_tokens()                     # D2H, syncs the engine stream
+        block = torch.from_numpy(toks).cuda(non_blocking=True)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, block)      # RCCL over xGMI: [B, 449] int32 per rank
+        else:
+            gathered.copy_(block)
+        return lens
+
+    for _ in range(args.warmup):
+        step()
+    log("warmup done; timing ...")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lens = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert (lens == n_dec).all(), lens
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    log(f"timed {args.steps} steps in {dt * 1e3:.1f} ms")
+    stage_ms, steps_done = model.batch_timings()
+    probe = {name: model.kernel_probe(which, 20) for which, name in ((0, "layer_gemv"), (1, "decode_attn"), (2, "lm_head"))}
+
+    if rank == 0:
+        audio_s = world * B * args.seconds * args.steps
+        ms_step = dt / args.steps * 1e3
+        dom_ms, dom_bytes = probe["layer_gemv"]
+        out = {
+            "metric": "audio-seconds/sec (RTF^-1) Qwen3-ASR-0.6B, 30 s@16 kHz, b=32 per GPU",
+            "value": round(audio_s / dt, 1),
+            "unit": "audio-seconds/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen3-ASR-0.6B geometry, {B} clips x {args.seconds:.0f} s per GPU "
+                                   f"(BASELINE metric's b=32; x8 GPUs = configs[2]), mel+encoder+prompt pass+"
+                                   f"{n_dec} forced greedy tokens, tokens gathered over RCCL",
+                       "clips_per_gpu": B, "clip_seconds": args.seconds, "decode_tokens": n_dec,
+                       "sharding": f"dp{world} (independent clips, weights replicated)"},
+            "rtf": round(dt / audio_s, 7),
+            "stage_ms": {"mel": round(stage_ms[0], 3), "encoder": round(stage_ms[1], 3),
+                         "prompt_pass": round(stage_ms[2], 3), "decode": round(stage_ms[3], 3),
+                         "decode_steps": steps_done},
+            "pcie_inclusive_value": round(world * B * args.seconds / (ms_step / 1e3 + h2d_s), 1),
+            "roofline": {"bound": "hbm", "kernel": "decode_gemv_kernel (the four weight-streaming launches of one decoder layer)",
+                         "achieved": round(dom_bytes / dom_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch_group": dom_bytes, "avg_ms_per_launch_group": round(dom_ms, 5),
+                         "other": {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)}
+                                   for k, v in probe.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, clips[0], n_dec)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    model.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,9 @@ int qasr_stt_vtable(qasr_engine* e, sc_stt_vtable_t* out);
 int qasr_batch_begin(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B,
                      const qasr_options* opt);          /* host -> HBM, builds the batch plan */
 int qasr_batch_run(qasr_engine* e);                     /* mel + encoder + prefill + greedy decode, async */
+/* Re-arm the resident batch (PCM + plans stay in HBM, greedy state is reset on the device) so that
+ * qasr_batch_run can be timed repeatedly without host->device traffic.  No reference counterpart. */
+int qasr_batch_rewind(qasr_engine* e);
 int qasr_batch_sync(qasr_engine* e);                    /* wait for the engine stream */
 int qasr_batch_tokens(qasr_engine* e, int32_t* tokens, int32_t* lens);   /* HBM -> host */
 /* per-stage device time of the last qasr_batch_run, milliseconds (HIP events on the engine stream):

@@ -129,6 +129,7 @@ int qasr_batch_begin(qasr_engine* e, const float* const* pcm, const size_t* n, s
     QASR_GUARD(e, e->impl->batch_begin(pcm, n, B, opt));
 }
 int qasr_batch_run(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_run()); }
+int qasr_batch_rewind(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_rewind()); }
 int qasr_batch_sync(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_sync()); }
 int qasr_batch_tokens(qasr_engine* e, int32_t* tokens, int32_t* lens) {
     if (!e || !tokens || !lens) return QASR_ERR_INVALID;

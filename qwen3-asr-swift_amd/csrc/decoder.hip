@@ -204,13 +204,12 @@ void Engine::reset_greedy_state(int max_tokens, bool ignore_eos) {
     // tokens = -1, lens = finished = 0, ctx_len = prompt_len, n_active = B
     QASR_HIP(hipMemsetAsync(gstate_.tokens, 0xff, (size_t)cfg_.max_batch * (cfg_.max_new_tokens + 1) * sizeof(int), stream_));
     QASR_HIP(hipMemsetAsync(gstate_.lens, 0, (size_t)2 * cfg_.max_batch * sizeof(int), stream_));
-    std::vector<int> init(cfg_.max_batch + 1, 0);
-    for (int b = 0; b < B; ++b) init[b] = h_ctx0_[b];
-    // ctx_len [max_batch] then n_active: two small copies from pageable memory are synchronous wrt host
-    QASR_HIP(hipMemcpyAsync(gstate_.ctx_len, init.data(), (size_t)cfg_.max_batch * sizeof(int), hipMemcpyHostToDevice, stream_));
-    int nact = B;
-    QASR_HIP(hipMemcpyAsync(gstate_.n_active, &nact, sizeof(int), hipMemcpyHostToDevice, stream_));
-    QASR_HIP(hipStreamSynchronize(stream_));
+    // ctx_len [max_batch] and n_active are contiguous in the state block: one copy from pinned memory
+    if (!h_ginit_.p) h_ginit_.alloc((size_t)(cfg_.max_batch + 1) * sizeof(int));
+    int* init = h_ginit_.as<int>();
+    for (int b = 0; b < cfg_.max_batch; ++b) init[b] = b < B ? h_ctx0_[b] : 0;
+    init[cfg_.max_batch] = B;
+    QASR_HIP(hipMemcpyAsync(gstate_.ctx_len, init, (size_t)(cfg_.max_batch + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
     steps_done_ = 0;
 }
 
@@ -346,6 +345,12 @@ void Engine::batch_run() {
     QASR_HIP(hipEventRecord(ev_[3], s));
     decode_loop();
     QASR_HIP(hipEventRecord(ev_[4], s));
+}
+
+void Engine::batch_rewind() {
+    if (batch_ <= 0 || h_ctx0_.empty()) throw std::runtime_error("batch_rewind: no resident batch");
+    QASR_HIP(hipStreamSynchronize(stream_));       // h_ginit_ is reused
+    reset_greedy_state(cur_max_tokens_, cur_ignore_eos_);
 }
 
 void Engine::batch_sync() { QASR_HIP(hipStreamSynchronize(stream_)); }

@@ -96,6 +96,7 @@ public:
     // batch pipeline (qasr_batch_*): H2D + plan | mel + encoder + prefill + greedy decode | D2H
     void batch_begin(const float* const* pcm, const size_t* n, size_t B, const qasr_options* opt);
     void batch_run();
+    void batch_rewind();
     void batch_sync();
     void batch_tokens(int32_t* tokens, int32_t* lens);
     void batch_timings(float ms[5], int32_t* n_steps);
@@ -202,6 +203,7 @@ private:
     bool use_graph_ = true;
     hipEvent_t ev_[6] = {};
     std::vector<int> h_ctx0_;
+    HostBuf h_ginit_;                                          // pinned: ctx_len init [max_batch] | n_active
 
     // ---- tokenizer -----------------------------------------------------------------------------
     std::unordered_map<int32_t, std::string> id_to_token_;

@@ -69,6 +69,7 @@ SIGNATURES = {
     "qasr_stt_vtable": (C.c_int, [_E, _P(ScSttVtable)]),
     "qasr_batch_begin": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, _P(QasrOptions)]),
     "qasr_batch_run": (C.c_int, [_E]),
+    "qasr_batch_rewind": (C.c_int, [_E]),
     "qasr_batch_sync": (C.c_int, [_E]),
     "qasr_batch_tokens": (C.c_int, [_E, _I, _I]),
     "qasr_batch_timings": (C.c_int, [_E, _F, _I]),
