@@ -61,6 +61,10 @@ struct DecGemvArgs {
 // Returns the number of workgroups (LOGITS: partial count per row).
 int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s);
 int decode_gemv_blocks(DecEpi epi, int N);
+// Decode-step form with the RMSNorm of the input fused into the activation staging (norm_w != null):
+// out = epi( rmsnorm(X) . W^T ).  `norm_scratch` [B][K] is only used by the generic fallback.
+int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* norm_w, float eps, bf16_t* norm_scratch,
+                             hipStream_t s);
 
 // One new token per batch row: q/k norm + RoPE at pos = ctx_len[b], append K/V to the cache,
 // attention of the rep = heads/kv_heads query heads over the cache (f32 softmax), out [B][heads*hd].

@@ -1,5 +1,6 @@
 // dec_kernels.hip -- text-decoder kernels (see dec_kernels.h).
 #include "dec_kernels.h"
+#include <cstdlib>
 
 namespace qasr {
 
@@ -317,6 +318,72 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
         throw std::invalid_argument("prefill attention: head_dim must be 32 or 128");
 }
 
+// accumulator layout: acc[t][b][j] = out[batch b*16 + fr][n0 + t*16 + fc*4 + j]
+template <int NT, int NB, int EPI>
+__device__ __forceinline__ void dec_epilogue(const DecGemvArgs& a, f32x4 (&acc)[NT][NB], int n0, int fr, int fc) {
+    if (EPI == DEC_EPI_BF16 || EPI == DEC_EPI_RESID) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = b * 16 + fr;
+                if (row < a.B) {
+                    bf16_t* p = a.out + (long)row * a.N + n0 + t * 16 + fc * 4;
+                    float4 v = make_float4(acc[t][b][0], acc[t][b][1], acc[t][b][2], acc[t][b][3]);
+                    if (EPI == DEC_EPI_RESID) {
+                        float4 r = load_bf16x4(p);
+                        v.x = r.x + bf16_round(v.x); v.y = r.y + bf16_round(v.y);
+                        v.z = r.z + bf16_round(v.z); v.w = r.w + bf16_round(v.w);
+                    }
+                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
+                }
+            }
+    } else if (EPI == DEC_EPI_SWIGLU) {
+        // rows come in blocks of 32: 16 gate rows then the 16 matching up rows -> tile pairs (2i, 2i+1)
+#pragma unroll
+        for (int t = 0; t + 1 < NT; t += 2)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = b * 16 + fr;
+                if (row < a.B) {
+                    float4 v;
+                    v.x = swiglu_bf16(acc[t][b][0], acc[t + 1][b][0]);
+                    v.y = swiglu_bf16(acc[t][b][1], acc[t + 1][b][1]);
+                    v.z = swiglu_bf16(acc[t][b][2], acc[t + 1][b][2]);
+                    v.w = swiglu_bf16(acc[t][b][3], acc[t + 1][b][3]);
+                    bf16_t* p = a.out + (long)row * (a.N / 2) + (n0 + t * 16) / 2 + fc * 4;
+                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
+                }
+            }
+    } else {   // DEC_EPI_LOGITS: bf16-rounded logits, per-block argmax with lowest-index ties
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int row = b * 16 + fr;
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + t * 16 + fc * 4 + j;
+                    const float v = bf16_round(acc[t][b][j]);
+                    if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
+                    if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+                }
+#pragma unroll
+            for (int ofs = 16; ofs < 64; ofs <<= 1) {
+                float ov = __shfl_xor(best, ofs, 64);
+                int oi = __shfl_xor(bidx, ofs, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (fc == 0 && row < a.B) {
+                a.part_val[(long)row * gridDim.x + blockIdx.x] = best;
+                a.part_idx[(long)row * gridDim.x + blockIdx.x] = bidx;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decode-step skinny GEMM:  out[b][n] = sum_k X[b][k] W[n][k],  b < B <= 16*NB.
 // Workgroup = 4 waves over 16*NT weight rows; wave w takes k-steps w, w+4, ... of 32 columns.  The
@@ -398,68 +465,139 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(DecGemvArgs a) {
                 f32x4 r = *reinterpret_cast<const f32x4*>(&s_red[w][t * NB + b][lane * 4]);
                 acc[t][b] += r;
             }
-    // accumulator layout: acc[t][b][j] = out[batch b*16 + fr][n0 + t*16 + fc*4 + j]
-    if (EPI == DEC_EPI_BF16 || EPI == DEC_EPI_RESID) {
+    dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode-step skinny GEMM, tuned form ("weights stationary in registers, activations in LDS").
+//   * every wave first issues ALL of its weight-fragment loads (KSW k-steps x NT row tiles, 16 B per
+//     lane each) so the whole weight matrix is in flight across the chip at once -- a 4..12 MB matrix
+//     is latency-, not bandwidth-limited, so memory-level parallelism is what matters;
+//   * while those are in flight the workgroup stages the activation rows into LDS (optionally
+//     applying RMSNorm: y = bf16(w * bf16(x * inv)) -- the separate norm launch disappears);
+//   * MFMA B fragments are then ds_read_b128 from the padded LDS image (row stride 2K + 16 bytes:
+//     16 batch rows x one 16-byte chunk cover all 64 banks once);
+//   * if the LDS image of all batch rows does not fit, rows are processed 16 at a time against the
+//     same register-resident weights.
+// k-steps are interleaved over the waves (wave w owns steps w, w + WAVES, ...).
+// ------------------------------------------------------------------------------------------------
+enum DecPro { DEC_PRO_COPY = 0, DEC_PRO_RMSNORM = 1 };
+
+struct DecGemv2Args {
+    DecGemvArgs g;
+    const bf16_t* norm_w;      // RMSNORM prologue: weight [K]
+    float eps;
+};
+
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a2) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const DecGemvArgs& a = a2.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    constexpr int K = KSW * WAVES * 32;                           // host checks a.K == K
+    constexpr int KCH = K / 8;                                    // 16-byte chunks per row
+    constexpr int XSTRIDE = 2 * K + 16;                           // bytes
+    constexpr int NPH = ALLROWS ? 1 : NB;                         // phases
+    constexpr int NBP = ALLROWS ? NB : 1;                         // batch tiles resident per phase
+    constexpr int RPP = 16 * NBP;
+    constexpr int TPR = WAVES * 64 / RPP;                         // threads sharing one activation row
+    constexpr int XI = KCH / TPR;                                 // staged 16-byte chunks per thread per phase
+    static_assert(TPR >= 1 && TPR <= 64 && (TPR & (TPR - 1)) == 0 && KCH % TPR == 0, "row staging geometry");
+    const int n0 = blockIdx.x * 16 * NT;
+    char* s_x = dsm;                                              // [RPP][XSTRIDE]
+    float* s_red = reinterpret_cast<float*>(dsm + (size_t)RPP * XSTRIDE);   // [WAVES-1][NT*NB][256]
+    // thread -> (row srow, column chunks scol + TPR*i): a row lives on TPR adjacent lanes of one wave, so
+    // its sum of squares needs log2(TPR) shuffles and no LDS round trip
+    const int srow = tid / TPR, scol = tid % TPR;
+    uint4 xr[XI];
+    auto issue_x = [&](int r0) {
+        const bool live = r0 + srow < a.B;
+        const bf16_t* xp = a.X + (long)(live ? r0 + srow : 0) * K + scol * 8;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int i = 0; i < XI; ++i) xr[i] = live ? *reinterpret_cast<const uint4*>(xp + i * TPR * 8) : make_uint4(0, 0, 0, 0);
+    };
+    // ---- 1. activation loads first (older in the in-order return queue), then ALL weight fragments ----
+    issue_x(0);
+    uint4 w[NT][KSW];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int row = b * 16 + fr;
-                if (row < a.B) {
-                    bf16_t* p = a.out + (long)row * a.N + n0 + t * 16 + fc * 4;
-                    float4 v = make_float4(acc[t][b][0], acc[t][b][1], acc[t][b][2], acc[t][b][3]);
-                    if (EPI == DEC_EPI_RESID) {
-                        float4 r = load_bf16x4(p);
-                        v.x = r.x + bf16_round(v.x); v.y = r.y + bf16_round(v.y);
-                        v.z = r.z + bf16_round(v.z); v.w = r.w + bf16_round(v.w);
-                    }
-                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
-                }
+    for (int t = 0; t < NT; ++t) {
+        const bf16_t* wp = a.W + (long)(n0 + t * 16 + fr) * K + fc * 8;
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) w[t][i] = *reinterpret_cast<const uint4*>(wp + (wave + WAVES * i) * 32);
+    }
+    f32x4 acc[NT][NB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        if (ph > 0) {
+            __syncthreads();                                      // previous phase's LDS reads are done
+            issue_x(ph * RPP);
+        }
+        // ---- 2. activation rows -> LDS (the weight loads stay in flight) -------------------------------
+        char* xrow = s_x + (size_t)srow * XSTRIDE + scol * 16;
+        if constexpr (PRO == DEC_PRO_RMSNORM) {
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
             }
-    } else if (EPI == DEC_EPI_SWIGLU) {
-        // rows come in blocks of 32: 16 gate rows then the 16 matching up rows -> tile pairs (2i, 2i+1)
 #pragma unroll
-        for (int t = 0; t + 1 < NT; t += 2)
+            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            const float inv = rsqrtf(ss / (float)K + a2.eps);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int row = b * 16 + fr;
-                if (row < a.B) {
-                    float4 v;
-                    v.x = swiglu_bf16(acc[t][b][0], acc[t + 1][b][0]);
-                    v.y = swiglu_bf16(acc[t][b][1], acc[t + 1][b][1]);
-                    v.z = swiglu_bf16(acc[t][b][2], acc[t + 1][b][2]);
-                    v.w = swiglu_bf16(acc[t][b][3], acc[t + 1][b][3]);
-                    bf16_t* p = a.out + (long)row * (a.N / 2) + (n0 + t * 16) / 2 + fc * 4;
-                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
-                }
+            for (int i = 0; i < XI; ++i) {
+                const uint4 nw = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+                const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
+                uint4 o;
+                bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) oe[j] = f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv));
+                *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
             }
-    } else {   // DEC_EPI_LOGITS: bf16-rounded logits, per-block argmax with lowest-index ties
+        } else {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int row = b * 16 + fr;
-            float best = -INFINITY;
-            int bidx = 0x7fffffff;
+            for (int i = 0; i < XI; ++i) *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = xr[i];
+        }
+        __syncthreads();
+        // ---- 3. MFMA: register-resident weights x LDS activations --------------------------------------
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+        for (int i = 0; i < KSW; ++i) {
+            const int kb = ((wave + WAVES * i) * 32 + fc * 8) * 2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + t * 16 + fc * 4 + j;
-                    const float v = bf16_round(acc[t][b][j]);
-                    if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
-                    if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
-                }
+            for (int b = 0; b < NBP; ++b) {
+                const uint4 xf = *reinterpret_cast<const uint4*>(s_x + (size_t)(b * 16 + fr) * XSTRIDE + kb);
 #pragma unroll
-            for (int ofs = 16; ofs < 64; ofs <<= 1) {
-                float ov = __shfl_xor(best, ofs, 64);
-                int oi = __shfl_xor(bidx, ofs, 64);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            if (fc == 0 && row < a.B) {
-                a.part_val[(long)row * gridDim.x + blockIdx.x] = best;
-                a.part_idx[(long)row * gridDim.x + blockIdx.x] = bidx;
+                for (int t = 0; t < NT; ++t)
+                    acc[t][ALLROWS ? b : ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(mfma_bf16x8, w[t][i]), __builtin_bit_cast(mfma_bf16x8, xf),
+                        acc[t][ALLROWS ? b : ph], 0, 0, 0);
             }
         }
     }
+    // ---- 4. cross-wave reduction in fixed order, epilogue on wave 0 ------------------------------------
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                *reinterpret_cast<f32x4*>(&s_red[((size_t)(wave - 1) * NT * NB + t * NB + b) * 256 + lane * 4]) = acc[t][b];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int wv = 0; wv < WAVES - 1; ++wv)
+                acc[t][b] += *reinterpret_cast<const f32x4*>(&s_red[((size_t)wv * NT * NB + t * NB + b) * 256 + lane * 4]);
+    dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc);
 }
 
 static int dec_nt(DecEpi epi, int N) {
@@ -482,7 +620,7 @@ static void dec_launch_nb(const DecGemvArgs& a, int blocks, hipStream_t s) {
     }
 }
 
-int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s) {
+static int decode_gemv_generic(DecEpi epi, const DecGemvArgs& a, hipStream_t s) {
     if (a.B <= 0) return 0;
     if (a.K % 32 != 0) throw std::invalid_argument("decode gemv: K must be a multiple of 32");
     const int nt = dec_nt(epi, a.N);
@@ -501,6 +639,89 @@ int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s) {
     return blocks;
 }
 
+int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s) { return decode_gemv_generic(epi, a, s); }
+
+// ---- tuned dispatch ---------------------------------------------------------------------------------
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS>
+constexpr size_t gemv2_lds() {
+    return (size_t)(ALLROWS ? 16 * NB : 16) * (2 * (KSW * WAVES * 32) + 16) + (size_t)(WAVES - 1) * NT * NB * 1024;
+}
+
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI>
+static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
+    constexpr size_t lds = gemv2_lds<NT, NB, WAVES, KSW, ALLROWS>();
+    if constexpr (lds > 156 * 1024) {
+        return false;
+    } else {
+        auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT)), dim3(WAVES * 64), lds, s, a2);
+        return true;
+    }
+}
+
+template <int NT, int WAVES, int KSW, int PRO, int EPI>
+static bool gemv2_nb(const DecGemv2Args& a2, hipStream_t s) {
+    const int nb = (a2.g.B + 15) / 16;
+    // all batch rows resident in LDS when they fit (LDS and staging registers), else 16 rows per phase
+    constexpr bool fit2 = gemv2_lds<NT, 2, WAVES, KSW, true>() <= 150 * 1024 && NT * KSW * 4 + 2 * KSW * 4 <= 170;
+    switch (nb) {
+        case 1: return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI>(a2, s);
+        case 2:
+            if constexpr (fit2) return gemv2_go<NT, 2, WAVES, KSW, true, PRO, EPI>(a2, s);
+            else return gemv2_go<NT, 2, WAVES, KSW, false, PRO, EPI>(a2, s);
+        case 3: return gemv2_go<NT, 3, WAVES, KSW, false, PRO, EPI>(a2, s);
+        case 4: return gemv2_go<NT, 4, WAVES, KSW, false, PRO, EPI>(a2, s);
+        default: return false;
+    }
+}
+
+template <int PRO, int EPI, int NT>
+static bool gemv2_k(const DecGemv2Args& a2, hipStream_t s) {
+    // (K -> waves x k-steps per wave): wide workgroups for the small-N / large-K matrices
+    switch (a2.g.K) {
+        case 1024:
+            if constexpr (EPI == DEC_EPI_LOGITS) return gemv2_nb<NT, 8, 4, PRO, EPI>(a2, s);
+            else return gemv2_nb<NT, 4, 8, PRO, EPI>(a2, s);
+        case 2048: return gemv2_nb<NT, 8, 8, PRO, EPI>(a2, s);
+        case 3072:            // K = intermediate size: never behind a norm
+            if constexpr (PRO == DEC_PRO_COPY) return gemv2_nb<NT, 8, 12, PRO, EPI>(a2, s);
+            else return false;
+        default: return false;
+    }
+}
+
+// Fused form used by the decode step: optional RMSNorm prologue (norm_w != null) + epilogue.
+// Falls back to [rmsnorm_rows +] the generic kernel for shapes without a tuned instantiation.
+int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* norm_w, float eps, bf16_t* norm_scratch,
+                             hipStream_t s) {
+    if (a.B <= 0) return 0;
+    const int nt = dec_nt(epi, a.N);
+    DecGemv2Args a2{a, norm_w, eps};
+    bool ok = false;
+    if (a.N % (16 * nt) == 0 && a.B <= 64) {
+        if (norm_w) {
+            if (epi == DEC_EPI_BF16) ok = gemv2_k<DEC_PRO_RMSNORM, DEC_EPI_BF16, 1>(a2, s);
+            else if (epi == DEC_EPI_SWIGLU) ok = gemv2_k<DEC_PRO_RMSNORM, DEC_EPI_SWIGLU, 2>(a2, s);
+            else if (epi == DEC_EPI_LOGITS && nt == 4) ok = gemv2_k<DEC_PRO_RMSNORM, DEC_EPI_LOGITS, 4>(a2, s);
+        } else {
+            if (epi == DEC_EPI_RESID) ok = gemv2_k<DEC_PRO_COPY, DEC_EPI_RESID, 1>(a2, s);
+            else if (epi == DEC_EPI_BF16) ok = gemv2_k<DEC_PRO_COPY, DEC_EPI_BF16, 1>(a2, s);
+        }
+    }
+    if (ok) return a.N / (16 * nt);
+    DecGemvArgs g = a;
+    if (norm_w) {
+        rmsnorm_rows_launch(a.X, norm_w, norm_scratch, a.B, a.K, eps, s);
+        g.X = norm_scratch;
+    }
+    return decode_gemv_generic(epi, g, s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decode attention: one workgroup per (kv head, batch row), 8 waves.  Phase 1: waves 0..rep-1 norm +
 // rope their query head, wave rep does the new key, wave rep+1 copies the new value; K/V are appended
@@ -512,7 +733,7 @@ int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s) {
 constexpr int DA_WAVES = 8;
 constexpr int DA_MAXREP = 4;
 
-template <int HD, int REP>
+template <int HD, int REP, int DA_UNR>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
     const bf16_t* __restrict__ qkv, const int* __restrict__ ctx_len, int heads, int kv_heads,
     const bf16_t* __restrict__ qn_w, const bf16_t* __restrict__ kn_w, float eps, const float* __restrict__ rope_cos,
@@ -597,20 +818,31 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
         }
     };
     const int ngroups = (pos + KPI - 1) / KPI;
-    for (int g = wave; g < ngroups; g += DA_WAVES) {
-        const int key = g * KPI + slot;
-        const bool valid = key < pos;
-        uint4 ku = make_uint4(0, 0, 0, 0), vu = make_uint4(0, 0, 0, 0);
-        if (valid) {
-            ku = *reinterpret_cast<const uint4*>(kb + (long)key * HD);
-            vu = *reinterpret_cast<const uint4*>(vb + (long)key * HD);
-        }
-        float kf[8], vf[8];
-        const bf16_t* ke = reinterpret_cast<const bf16_t*>(&ku);
-        const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vu);
+    for (int g0 = wave; g0 < ngroups; g0 += DA_WAVES * DA_UNR) {
+        uint4 ku[DA_UNR], vu[DA_UNR];
+        bool valid[DA_UNR];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[j] = bf16_to_f32(ke[j]); vf[j] = bf16_to_f32(ve[j]); }
-        absorb(kf, vf, valid);
+        for (int u = 0; u < DA_UNR; ++u) {
+            const int key = (g0 + u * DA_WAVES) * KPI + slot;
+            valid[u] = key < pos;
+            ku[u] = make_uint4(0, 0, 0, 0);
+            vu[u] = make_uint4(0, 0, 0, 0);
+            if (valid[u]) {
+                ku[u] = *reinterpret_cast<const uint4*>(kb + (long)key * HD);
+                vu[u] = *reinterpret_cast<const uint4*>(vb + (long)key * HD);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DA_UNR; ++u) {
+            if (g0 + u * DA_WAVES < ngroups) {                     // wave-uniform
+                float kf[8], vf[8];
+                const bf16_t* ke = reinterpret_cast<const bf16_t*>(&ku[u]);
+                const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vu[u]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kf[j] = bf16_to_f32(ke[j]); vf[j] = bf16_to_f32(ve[j]); }
+                absorb(kf, vf, valid[u]);
+            }
+        }
     }
     if (wave == DA_WAVES - 1) {      // the token's own key/value (slot 0 lanes only)
         float kf[8], vf[8];
@@ -666,11 +898,18 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     const int rep = heads / kv_heads;
     const float scale = 1.0f / sqrtf((float)hd);
     dim3 grid(kv_heads, B), block(DA_WAVES * 64);
-    if (hd == 128 && rep == 2)
-        hipLaunchKernelGGL((decode_attention_kernel<128, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
+    static const int unr = getenv("QASR_DA_UNR") ? atoi(getenv("QASR_DA_UNR")) : 1;   // tuning knob (A/B)
+    if (hd == 128 && rep == 2 && unr == 1)
+        hipLaunchKernelGGL((decode_attention_kernel<128, 2, 1>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
+                           eps, rope_cos, rope_sin, cache, out, scale);
+    else if (hd == 128 && rep == 2 && unr == 2)
+        hipLaunchKernelGGL((decode_attention_kernel<128, 2, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
+                           eps, rope_cos, rope_sin, cache, out, scale);
+    else if (hd == 128 && rep == 2)
+        hipLaunchKernelGGL((decode_attention_kernel<128, 2, 4>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
                            eps, rope_cos, rope_sin, cache, out, scale);
     else if (hd == 32 && rep == 2)
-        hipLaunchKernelGGL((decode_attention_kernel<32, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
+        hipLaunchKernelGGL((decode_attention_kernel<32, 2, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
                            eps, rope_cos, rope_sin, cache, out, scale);
     else
         throw std::invalid_argument("decode attention: unsupported (head_dim, heads/kv_heads)");

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace qasr {
 
@@ -139,6 +140,13 @@ void Engine::finalize_decoder() {
     gstate_.eos = cfg_.tok_im_end;
     for (auto& e : ev_)
         if (!e) QASR_HIP(hipEventCreate(&e));
+    if (!fork_ev_) {
+        QASR_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) {
+            QASR_HIP(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+            QASR_HIP(hipEventCreateWithFlags(&join_ev_[i], hipEventDisableTiming));
+        }
+    }
     QASR_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -213,15 +221,14 @@ void Engine::reset_greedy_state(int max_tokens, bool ignore_eos) {
     steps_done_ = 0;
 }
 
-void Engine::run_lm_head(bool want_logits) {
+void Engine::run_lm_head(bool want_logits, int r0, int nr, hipStream_t s) {
     const int H = cfg_.hidden;
-    rmsnorm_rows_launch(d_dx_.as<bf16_t>(), decw_.norm, d_dh_.as<bf16_t>(), batch_, H, cfg_.rms_eps, stream_);
     DecGemvArgs a{};
-    a.W = decw_.embed; a.X = d_dh_.as<bf16_t>(); a.B = batch_; a.N = cfg_.vocab; a.K = H;
-    a.logits = want_logits ? d_logits_.as<float>() : nullptr;
-    a.part_val = d_part_val_.as<float>();
-    a.part_idx = d_part_idx_.as<int>();
-    decode_gemv_launch(DEC_EPI_LOGITS, a, stream_);
+    a.W = decw_.embed; a.X = d_dx_.as<bf16_t>() + (size_t)r0 * H; a.B = nr; a.N = cfg_.vocab; a.K = H;
+    a.logits = want_logits ? d_logits_.as<float>() + (size_t)r0 * cfg_.vocab : nullptr;
+    a.part_val = d_part_val_.as<float>() + (size_t)r0 * n_parts_;
+    a.part_idx = d_part_idx_.as<int>() + (size_t)r0 * n_parts_;
+    decode_gemv_fused_launch(DEC_EPI_LOGITS, a, decw_.norm, cfg_.rms_eps, d_dh_.as<bf16_t>() + (size_t)r0 * H, s);
 }
 
 void Engine::run_prefill(bool want_logits) {
@@ -247,37 +254,80 @@ void Engine::run_prefill(bool want_logits) {
     }
     // last position of every clip -> decode rows (Qwen3ASR.swift:254-256)
     gather_rows_launch(x, d_p_last_, d_dx_.as<bf16_t>(), batch_, H, s);
-    run_lm_head(want_logits);
+    run_lm_head(want_logits, 0, batch_, s);
     QASR_HIP(hipGetLastError());
 }
 
-void Engine::run_decode_step(bool want_logits, bool greedy) {
+GreedyState Engine::greedy_rows(int r0) const {
+    GreedyState g = gstate_;
+    g.tokens += (size_t)r0 * (cfg_.max_new_tokens + 1);
+    g.lens += r0;
+    g.finished += r0;
+    g.ctx_len += r0;
+    return g;
+}
+
+// One decode step for batch rows [r0, r0 + nr) on stream s.  Rows are independent, so a step can be
+// issued as several row groups on parallel graph branches (see decode_loop).
+void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s) {
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
-    hipStream_t s = stream_;
-    bf16_t *x = d_dx_.as<bf16_t>(), *h = d_dh_.as<bf16_t>(), *qkv = d_dqkv_.as<bf16_t>(), *at = d_dattn_.as<bf16_t>();
-    bf16_t* act = d_dact_.as<bf16_t>();
-    const int B = batch_;
+    bf16_t* x = d_dx_.as<bf16_t>() + (size_t)r0 * H;
+    bf16_t* h = d_dh_.as<bf16_t>() + (size_t)r0 * H;
+    bf16_t* qkv = d_dqkv_.as<bf16_t>() + (size_t)r0 * nh * hd;
+    bf16_t* at = d_dattn_.as<bf16_t>() + (size_t)r0 * nq;
+    bf16_t* act = d_dact_.as<bf16_t>() + (size_t)r0 * I;
+    const GreedyState gs = greedy_rows(r0);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
         KVLayout kv{kcache_[l]->as<bf16_t>(), vcache_[l]->as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd};
-        rmsnorm_rows_launch(x, L.ln1, h, B, H, cfg_.rms_eps, s);
+        kv.k += kv.off(r0, 0, 0);
+        kv.v += kv.off(r0, 0, 0);
         DecGemvArgs a{};
-        a.W = L.wqkv; a.X = h; a.B = B; a.N = nh * hd; a.K = H; a.out = qkv;
-        decode_gemv_launch(DEC_EPI_BF16, a, s);
-        decode_attention_launch(qkv, gstate_.ctx_len, B, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
+        a.W = L.wqkv; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
+        decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, h, s);
+        decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
                                 d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv, at, s);
         a.W = L.wo; a.X = at; a.N = H; a.K = nq; a.out = x;
-        decode_gemv_launch(DEC_EPI_RESID, a, s);
-        rmsnorm_rows_launch(x, L.ln2, h, B, H, cfg_.rms_eps, s);
-        a.W = L.wgu; a.X = h; a.N = 2 * I; a.K = H; a.out = act;
-        decode_gemv_launch(DEC_EPI_SWIGLU, a, s);
+        decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
+        a.W = L.wgu; a.X = x; a.N = 2 * I; a.K = H; a.out = act;
+        decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, h, s);
         a.W = L.wdown; a.X = act; a.N = H; a.K = I; a.out = x;
-        decode_gemv_launch(DEC_EPI_RESID, a, s);
+        decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
     }
-    run_lm_head(want_logits);
+    run_lm_head(want_logits, r0, nr, s);
     if (greedy)
-        greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, B, 1, decw_.embed,
-                               d_dx_.as<bf16_t>(), H, s);
+        greedy_finalize_launch(d_part_val_.as<float>() + (size_t)r0 * n_parts_, d_part_idx_.as<int>() + (size_t)r0 * n_parts_,
+                               n_parts_, gs, nr, 1, decw_.embed, x, H, s);
+}
+
+// A whole step = `split` row groups.  The small-batch decode kernels are latency-bound (a 4..12 MB weight
+// matrix per launch cannot fill the chip), so independent row groups issued on parallel branches overlap
+// one group's weight streaming with another's attention; the second reader of a layer's weights is served
+// from the Infinity Cache.
+void Engine::issue_decode_step(int split) {
+    const int B = batch_;
+    if (split <= 1 || B < 2 * 16) {
+        run_decode_step(false, true, 0, B, stream_);
+        return;
+    }
+    if (split > 4) split = 4;
+    // row groups are multiples of 16 rows (one MFMA batch tile) except the last
+    const int tiles = (B + 15) / 16;
+    if (split > tiles) split = tiles;
+    QASR_HIP(hipEventRecord(fork_ev_, stream_));
+    int r0 = 0;
+    for (int i = 0; i < split; ++i) {
+        const int t = tiles / split + (i < tiles % split ? 1 : 0);
+        const int nr = std::min(B - r0, t * 16);
+        hipStream_t s = i == 0 ? stream_ : side_[i - 1];
+        if (i > 0) QASR_HIP(hipStreamWaitEvent(s, fork_ev_, 0));
+        run_decode_step(false, true, r0, nr, s);
+        if (i > 0) {
+            QASR_HIP(hipEventRecord(join_ev_[i - 1], s));
+            QASR_HIP(hipStreamWaitEvent(stream_, join_ev_[i - 1], 0));
+        }
+        r0 += nr;
+    }
 }
 
 // Greedy loop (Qwen3ASR.swift:344-389): token 0 comes from the prompt pass; every further token costs
@@ -287,13 +337,15 @@ void Engine::run_decode_step(bool want_logits, bool greedy) {
 void Engine::decode_loop() {
     const int max_steps = cur_max_tokens_ - 1;
     if (max_steps <= 0) return;
-    const long key = ((long)batch_ << 32) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
+    static const int split_env = getenv("QASR_DECODE_SPLIT") ? atoi(getenv("QASR_DECODE_SPLIT")) : 2;
+    const int split = split_env;
+    const long key = ((long)batch_ << 32) | ((long)split << 24) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
     if (use_graph_ && (graph_exec_ == nullptr || graph_key_ != key)) {
         if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
         hipGraph_t g = nullptr;
         QASR_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         try {
-            run_decode_step(false, true);
+            issue_decode_step(split);
         } catch (...) {
             (void)hipStreamEndCapture(stream_, &g);
             if (g) (void)hipGraphDestroy(g);
@@ -307,7 +359,7 @@ void Engine::decode_loop() {
     int h_active = batch_;
     for (int step = 0; step < max_steps; ++step) {
         if (use_graph_) QASR_HIP(hipGraphLaunch(graph_exec_, stream_));
-        else run_decode_step(false, true);
+        else issue_decode_step(split);
         ++steps_done_;
         if (!cur_ignore_eos_ && (step % 8 == 7)) {
             QASR_HIP(hipMemcpyAsync(&h_active, gstate_.n_active, sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -386,22 +438,23 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         DecGemvArgs a{};
         a.B = batch_;
         if (which == 0) {
-            a.W = L.wqkv; a.X = d_dh_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
-            decode_gemv_launch(DEC_EPI_BF16, a, s);
+            // the same four launches as run_decode_step (residual epilogues write a scratch row block)
+            a.W = L.wqkv; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
+            decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
             a.W = L.wo; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();
-            decode_gemv_launch(DEC_EPI_BF16, a, s);
-            a.W = L.wgu; a.X = d_dh_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
-            decode_gemv_launch(DEC_EPI_SWIGLU, a, s);
+            decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
+            a.W = L.wgu; a.X = d_dx_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
+            decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
             a.W = L.wdown; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
-            decode_gemv_launch(DEC_EPI_BF16, a, s);
+            decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
         } else if (which == 1) {
             decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, batch_, cfg_.heads, cfg_.kv_heads, hd, L.qn,
                                     L.kn, cfg_.rms_eps, d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv,
                                     d_dattn_.as<bf16_t>(), s);
         } else {
-            a.W = decw_.embed; a.X = d_dh_.as<bf16_t>(); a.N = cfg_.vocab; a.K = H;
+            a.W = decw_.embed; a.X = d_dx_.as<bf16_t>(); a.N = cfg_.vocab; a.K = H;
             a.part_val = d_part_val_.as<float>(); a.part_idx = d_part_idx_.as<int>();
-            decode_gemv_launch(DEC_EPI_LOGITS, a, s);
+            decode_gemv_fused_launch(DEC_EPI_LOGITS, a, decw_.norm, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
         }
     };
     for (int i = 0; i < 3; ++i) body();
@@ -455,7 +508,7 @@ void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
         *idx.as<int>() = tokens[i];
         QASR_HIP(hipMemcpyAsync(didx.p, idx.p, sizeof(int), hipMemcpyHostToDevice, stream_));
         gather_rows_launch(decw_.embed, didx.as<int>(), d_dx_.as<bf16_t>(), 1, cfg_.hidden, stream_);
-        run_decode_step(true, false);
+        run_decode_step(true, false, 0, 1, stream_);
         hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(64), 0, stream_, gstate_.ctx_len, 1, 1);
         QASR_HIP(hipMemcpyAsync(logits + (size_t)i * cfg_.vocab, d_logits_.p, (size_t)cfg_.vocab * sizeof(float),
                                 hipMemcpyDeviceToHost, stream_));

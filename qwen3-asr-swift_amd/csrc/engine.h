@@ -124,8 +124,10 @@ private:
     void finalize_decoder();
     void plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio);
     void run_prefill(bool want_logits);
-    void run_decode_step(bool want_logits, bool greedy);
-    void run_lm_head(bool want_logits);
+    void run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s);
+    void issue_decode_step(int split);
+    GreedyState greedy_rows(int r0) const;
+    void run_lm_head(bool want_logits, int r0, int nr, hipStream_t s);
     void reset_greedy_state(int max_tokens, bool ignore_eos);
     void decode_loop();
 
@@ -202,6 +204,8 @@ private:
     long graph_key_ = -1;
     bool use_graph_ = true;
     hipEvent_t ev_[6] = {};
+    hipStream_t side_[3] = {};                                 // parallel decode row groups
+    hipEvent_t fork_ev_ = nullptr, join_ev_[3] = {};
     std::vector<int> h_ctx0_;
     HostBuf h_ginit_;                                          // pinned: ctx_len init [max_batch] | n_active
 
