@@ -1,0 +1,70 @@
+"""Utterance-batch data parallelism on CPU: world_size 2 over gloo.  The per-rank engine is replaced
+by a deterministic stand-in (there is no GPU here); what is tested is the product's shard / gather
+logic (qasr.dist): contiguous partition, ragged tail, fixed-shape token-block all_gather, order."""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from qasr import dist as qd
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 5, 8, 31, 256):
+        for world in (1, 2, 3, 8):
+            spans = [qd.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class _FakeCfg:
+    max_new_tokens = 6
+
+
+class _FakeModel:
+    """Token stream = f(clip) only, like the real engine (clips are independent)."""
+    cfg = _FakeCfg()
+
+    def transcribe_batch(self, clips, **opt):
+        return [[int(c[0] * 1000) % 97 + i for i in range(1 + int(c[1]) % 6)] for c in clips]
+
+
+def _worker(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clips = [np.array([0.001 * (k + 1), k], dtype=np.float32) for k in range(n_clips)]
+        out = qd.transcribe_sharded(_FakeModel(), clips)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n_clips", [1, 4, 7])
+def test_sharded_transcribe_world2(n_clips):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    clips = [np.array([0.001 * (k + 1), k], dtype=np.float32) for k in range(n_clips)]
+    expect = _FakeModel().transcribe_batch(clips)
+    assert results[0] == expect and results[1] == expect

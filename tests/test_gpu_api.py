@@ -1,0 +1,188 @@
+"""C-ABI surface on the GPU: detokeniser KATs (reference's own unit-test vectors), transcribe() text
+contract, speech-core vtable adapter, safetensors / MLX-quantised checkpoint loading, error codes,
+unload / memory footprint (R9, R10 and the boundary rows of SURVEY.md section 8b)."""
+import ctypes as C
+import json
+import os
+import numpy as np
+import pytest
+import torch
+from conftest import GOLDEN
+from oracle import config as OC, tokenizer as otok
+from qasr import _lib, synth, config as QC
+from qasr.model import Qwen3ASRModel
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(GOLDEN, "kat_reference_tests.json"), encoding="utf-8"))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth.synth_state_dict(QC.AUDIO_TINY, QC.TEXT_TINY, seed=3, init="stress")
+
+
+@pytest.fixture(scope="module")
+def model(sd):
+    m = Qwen3ASRModel.from_state_dict(sd, preset="tiny", max_audio_seconds=10, max_new_tokens=32)
+    yield m
+    m.close()
+
+
+def _token_map(case):
+    b2u = otok.byte_to_unicode()
+    m = {int(k): "".join(b2u[b] for b in bs) for k, bs in case.get("map_bytes", {}).items()}
+    m.update({int(k): s for k, s in case.get("map_literal", {}).items()})
+    return m
+
+
+@pytest.mark.parametrize("case", KAT["tokenizer_decode"], ids=lambda c: c["name"])
+def test_detokenize_kats(sd, case):
+    m = Qwen3ASRModel.from_state_dict(sd, preset="tiny", max_audio_seconds=2, max_new_tokens=8)
+    try:
+        m.set_vocab(_token_map(case))
+        got = m.detokenize(case["tokens"])
+        want = otok.strip_asr_prefix(otok.decode(case["tokens"], _token_map(case)))
+        if "expect" in case and "<asr_text>" not in case["expect"]:
+            assert got == case["expect"]
+        elif "expect_contains" in case:
+            assert case["expect_contains"] in got
+        assert got == want
+    finally:
+        m.close()
+
+
+def test_transcribe_text_contract(model, sd):
+    vocab = {i: chr(ord("a") + i % 26) for i in range(QC.TEXT_TINY.vocab)}
+    vocab[7] = "<asr_text>"
+    vocab[501] = "<|im_end|>"
+    model.set_vocab(vocab)
+    pcm = synth.synth_waveform(0, 1.5)
+    toks = model.transcribe_tokens(pcm, max_tokens=8, ignore_eos=True)
+    text = model.transcribe(pcm, max_tokens=8)
+    natural = model.transcribe_tokens(pcm, max_tokens=8)
+    assert natural == toks[:len(natural)]
+    assert text == otok.strip_asr_prefix(otok.decode(natural, vocab))
+    assert model.transcribe(pcm, sample_rate=24000).startswith("[qasr error:")      # non-throwing, like the reference
+    assert model.transcribe(np.zeros(0, np.float32)).startswith("[qasr error:")
+    assert model.input_sample_rate == 16000
+
+
+def test_stt_vtable(model):
+    vt = _lib.ScSttVtable()
+    assert model.lib.qasr_stt_vtable(model.h, C.byref(vt)) == 0
+    assert vt.input_sample_rate(vt.context) == 16000
+    assert not vt.begin_stream and not vt.push_chunk and not vt.cancel_stream
+    pcm = synth.synth_waveform(2, 1.0)
+    res = vt.transcribe(vt.context, pcm.ctypes.data_as(C.POINTER(C.c_float)), pcm.shape[0], 16000)
+    assert res.text.decode() == model.transcribe(pcm, max_tokens=32)     # vtable uses the engine's cap
+    assert res.language == b"" and res.confidence == 0.0 and res.start_time == 0.0 and res.end_time == 0.0
+
+
+def test_errors_and_capacity(model):
+    lib, h = model.lib, model.h
+    big = np.zeros(16000 * 11, np.float32)
+    toks = np.zeros((1, 33), np.int32)
+    lens = np.zeros(1, np.int32)
+    ptr = (C.POINTER(C.c_float) * 1)(big.ctypes.data_as(C.POINTER(C.c_float)))
+    n = (C.c_size_t * 1)(big.shape[0])
+    rc = lib.qasr_transcribe_batch(h, ptr, n, 1, 16000, None, toks.ctypes.data_as(C.POINTER(C.c_int32)),
+                                   lens.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 5 and b"max_audio_seconds" in lib.qasr_last_error(h)            # QASR_ERR_CAPACITY
+    o = _lib.QasrOptions()
+    o.max_tokens = 1000
+    small = synth.synth_waveform(0, 0.5)
+    ptr = (C.POINTER(C.c_float) * 1)(small.ctypes.data_as(C.POINTER(C.c_float)))
+    n = (C.c_size_t * 1)(small.shape[0])
+    assert lib.qasr_transcribe_batch(h, ptr, n, 1, 16000, C.byref(o), toks.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     lens.ctypes.data_as(C.POINTER(C.c_int32))) == 5
+    n0 = (C.c_size_t * 1)(0)
+    assert lib.qasr_transcribe_batch(h, ptr, n0, 1, 16000, None, toks.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     lens.ctypes.data_as(C.POINTER(C.c_int32))) == 6   # QASR_ERR_EMPTY_AUDIO
+
+
+def test_unload_and_footprint(sd):
+    m = Qwen3ASRModel.from_state_dict(sd, preset="tiny", max_audio_seconds=2, max_new_tokens=8)
+    try:
+        assert m.is_loaded
+        want = sum(t.numel() * 2 for t in sd.values())
+        assert m.memory_footprint == want
+        m.unload()
+        assert not m.is_loaded and m.memory_footprint == 0
+        assert m.transcribe(synth.synth_waveform(0, 0.5), max_tokens=8).startswith("[qasr error:")
+    finally:
+        m.close()
+
+
+def _mlx_quantize(w, bits, group=64):
+    """Affine group quantisation in the layout the reference's checkpoints use (PreQuantizedEmbedding.swift:
+    22-29): uint32 words holding 32/bits values LSB-first, per-group scale/bias; w ~= q*scale + bias."""
+    w = w.to(torch.float32).numpy()
+    out, inn = w.shape
+    g = w.reshape(out, inn // group, group)
+    lo, hi = g.min(-1), g.max(-1)
+    scale = np.maximum((hi - lo) / (2 ** bits - 1), 1e-8).astype(np.float32)
+    scale = torch.from_numpy(scale).to(torch.bfloat16).to(torch.float32).numpy()
+    bias = torch.from_numpy(lo.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+    q = np.clip(np.round((g - bias[..., None]) / scale[..., None]), 0, 2 ** bits - 1).astype(np.uint32).reshape(out, inn)
+    per = 32 // bits
+    packed = np.zeros((out, inn // per), dtype=np.uint32)
+    for j in range(per):
+        packed |= q[:, j::per] << np.uint32(bits * j)
+    deq = (q.reshape(out, inn // group, group).astype(np.float32) * scale[..., None] + bias[..., None]).reshape(out, inn)
+    return packed, scale, bias, torch.from_numpy(deq).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+def test_safetensors_and_mlx_quantised_checkpoint(tmp_path, sd, bits):
+    from safetensors.torch import save_file
+    tensors, expect = {}, dict(sd)
+    for name, t in sd.items():
+        quant = name.startswith("model.") and name.endswith("proj.weight") or name == "model.embed_tokens.weight"
+        if quant and t.shape[1] % 64 == 0:
+            packed, scale, bias, deq = _mlx_quantize(t, bits)
+            stem = name[:-len(".weight")]
+            tensors[name] = torch.from_numpy(packed.view(np.int32)).view(torch.int32)
+            tensors[stem + ".scales"] = torch.from_numpy(scale).to(torch.bfloat16)
+            tensors[stem + ".biases"] = torch.from_numpy(bias).to(torch.bfloat16)
+            expect[name] = deq
+        elif name.startswith("audio_tower.") and name.endswith(".bias"):
+            tensors[name] = t.to(torch.float16)            # mixed on-disk float dtypes
+            expect[name] = t.to(torch.float16).to(torch.bfloat16)
+        elif name.endswith("layer_norm.weight"):
+            tensors[name] = t.to(torch.float32)
+        else:
+            tensors[name] = t
+    keys = sorted(tensors)
+    half = len(keys) // 2
+    # safetensors has no uint32 in older torch: store as int32 and patch the dtype string in the header
+    for i, part in enumerate((keys[:half], keys[half:])):
+        path = tmp_path / f"model-0000{i + 1}-of-00002.safetensors"
+        save_file({k: tensors[k].contiguous() for k in part}, str(path))
+        raw = path.read_bytes()
+        hlen = int.from_bytes(raw[:8], "little")
+        header = json.loads(raw[8:8 + hlen])
+        for k, v in header.items():
+            if k != "__metadata__" and v["dtype"] == "I32":
+                v["dtype"] = "U32"
+        hb = json.dumps(header, separators=(",", ":")).encode()
+        hb += b" " * (hlen - len(hb))
+        assert len(hb) == hlen
+        path.write_bytes(raw[:8] + hb + raw[8 + hlen:])
+    (tmp_path / "vocab.json").write_text(json.dumps({"a": 0, "b": 1, "<asr_text>": 7}))
+    (tmp_path / "tokenizer_config.json").write_text(json.dumps({"added_tokens_decoder": {"501": {"content": "<|im_end|>"}}}))
+    m = Qwen3ASRModel(preset="tiny", model_dir=str(tmp_path), max_audio_seconds=4, max_new_tokens=16, bits=bits)
+    ref = Qwen3ASRModel.from_state_dict(expect, preset="tiny", max_audio_seconds=4, max_new_tokens=16)
+    try:
+        assert m.is_loaded
+        pcm = synth.synth_waveform(1, 2.0)
+        assert m.transcribe_tokens(pcm, max_tokens=10, ignore_eos=True) == ref.transcribe_tokens(pcm, max_tokens=10, ignore_eos=True)
+        assert m.detokenize([0, 1, 501, 7, 1, 0]) == "ba"
+    finally:
+        m.close()
+        ref.close()
+
+
+def test_missing_checkpoint_dir():
+    with pytest.raises(Exception) as ei:
+        Qwen3ASRModel(preset="tiny", model_dir="/nonexistent/dir")
+    assert "qasr_create failed" in str(ei.value)
