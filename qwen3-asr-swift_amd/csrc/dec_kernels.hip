@@ -320,7 +320,8 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
 
 // accumulator layout: acc[t][b][j] = out[batch b*16 + fr][n0 + t*16 + fc*4 + j]
 template <int NT, int NB, int EPI>
-__device__ __forceinline__ void dec_epilogue(const DecGemvArgs& a, f32x4 (&acc)[NT][NB], int n0, int fr, int fc) {
+__device__ __forceinline__ void dec_epilogue(const DecGemvArgs& a, f32x4 (&acc)[NT][NB], int n0, int fr, int fc,
+                                             const uint2 (*resid)[NB] = nullptr) {
     if (EPI == DEC_EPI_BF16 || EPI == DEC_EPI_RESID) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -331,7 +332,14 @@ __device__ __forceinline__ void dec_epilogue(const DecGemvArgs& a, f32x4 (&acc)[
                     bf16_t* p = a.out + (long)row * a.N + n0 + t * 16 + fc * 4;
                     float4 v = make_float4(acc[t][b][0], acc[t][b][1], acc[t][b][2], acc[t][b][3]);
                     if (EPI == DEC_EPI_RESID) {
-                        float4 r = load_bf16x4(p);
+                        float4 r;
+                        if (resid) {      // residual fetched at kernel start (saves a memory round trip)
+                            const uint2 u = resid[t][b];
+                            r = make_float4(bf16_to_f32((bf16_t)(u.x & 0xffff)), bf16_to_f32((bf16_t)(u.x >> 16)),
+                                            bf16_to_f32((bf16_t)(u.y & 0xffff)), bf16_to_f32((bf16_t)(u.y >> 16)));
+                        } else {
+                            r = load_bf16x4(p);
+                        }
                         v.x = r.x + bf16_round(v.x); v.y = r.y + bf16_round(v.y);
                         v.z = r.z + bf16_round(v.z); v.w = r.w + bf16_round(v.w);
                     }
@@ -511,10 +519,15 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     const int srow = tid / TPR, scol = tid % TPR;
     uint4 xr[XI];
     auto issue_x = [&](int r0) {
+        // unconditional loads (clamped row), zeroed afterwards by a select: no branch, no per-load drain
         const bool live = r0 + srow < a.B;
         const bf16_t* xp = a.X + (long)(live ? r0 + srow : 0) * K + scol * 8;
 #pragma unroll
-        for (int i = 0; i < XI; ++i) xr[i] = live ? *reinterpret_cast<const uint4*>(xp + i * TPR * 8) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+        if (!live) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xr[i] = make_uint4(0, 0, 0, 0);
+        }
     };
     // ---- 1. activation loads first (older in the in-order return queue), then ALL weight fragments ----
     issue_x(0);
@@ -524,6 +537,18 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
         const bf16_t* wp = a.W + (long)(n0 + t * 16 + fr) * K + fc * 8;
 #pragma unroll
         for (int i = 0; i < KSW; ++i) w[t][i] = *reinterpret_cast<const uint4*>(wp + (wave + WAVES * i) * 32);
+    }
+    uint2 rsd[NT][NB];
+    if constexpr (EPI == DEC_EPI_RESID) {
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int row = b * 16 + fr;
+                    rsd[t][b] = *reinterpret_cast<const uint2*>(a.out + (long)(row < a.B ? row : 0) * a.N + n0 + t * 16 + fc * 4);
+                }
+        }
     }
     f32x4 acc[NT][NB];
 #pragma unroll
@@ -597,7 +622,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
 #pragma unroll
             for (int wv = 0; wv < WAVES - 1; ++wv)
                 acc[t][b] += *reinterpret_cast<const f32x4*>(&s_red[((size_t)wv * NT * NB + t * NB + b) * 256 + lane * 4]);
-    dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc);
+    if constexpr (EPI == DEC_EPI_RESID) dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc, rsd);
+    else dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc);
 }
 
 static int dec_nt(DecEpi epi, int N) {
@@ -823,14 +849,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
         bool valid[DA_UNR];
 #pragma unroll
         for (int u = 0; u < DA_UNR; ++u) {
+            // unconditional loads from a clamped row: a load inside `if (valid)` makes hipcc branch around it
+            // and drain vmcnt per element, which serialises the whole unrolled group
             const int key = (g0 + u * DA_WAVES) * KPI + slot;
             valid[u] = key < pos;
-            ku[u] = make_uint4(0, 0, 0, 0);
-            vu[u] = make_uint4(0, 0, 0, 0);
-            if (valid[u]) {
-                ku[u] = *reinterpret_cast<const uint4*>(kb + (long)key * HD);
-                vu[u] = *reinterpret_cast<const uint4*>(vb + (long)key * HD);
-            }
+            const int kc = valid[u] ? key : 0;
+            ku[u] = *reinterpret_cast<const uint4*>(kb + (long)kc * HD);
+            vu[u] = *reinterpret_cast<const uint4*>(vb + (long)kc * HD);
         }
 #pragma unroll
         for (int u = 0; u < DA_UNR; ++u) {
@@ -898,7 +923,7 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     const int rep = heads / kv_heads;
     const float scale = 1.0f / sqrtf((float)hd);
     dim3 grid(kv_heads, B), block(DA_WAVES * 64);
-    static const int unr = getenv("QASR_DA_UNR") ? atoi(getenv("QASR_DA_UNR")) : 1;   // tuning knob (A/B)
+    static const int unr = getenv("QASR_DA_UNR") ? atoi(getenv("QASR_DA_UNR")) : 4;   // tuning knob (A/B)
     if (hd == 128 && rep == 2 && unr == 1)
         hipLaunchKernelGGL((decode_attention_kernel<128, 2, 1>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
                            eps, rope_cos, rope_sin, cache, out, scale);

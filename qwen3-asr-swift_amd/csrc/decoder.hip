@@ -306,19 +306,20 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
 // from the Infinity Cache.
 void Engine::issue_decode_step(int split) {
     const int B = batch_;
-    if (split <= 1 || B < 2 * 16) {
+    static const int gran = getenv("QASR_DECODE_GRAN") ? atoi(getenv("QASR_DECODE_GRAN")) : 16;
+    if (split <= 1 || B < 2 * gran) {
         run_decode_step(false, true, 0, B, stream_);
         return;
     }
     if (split > 4) split = 4;
-    // row groups are multiples of 16 rows (one MFMA batch tile) except the last
-    const int tiles = (B + 15) / 16;
+    // row groups are multiples of `gran` rows (16 = one MFMA batch tile) except the last
+    const int tiles = (B + gran - 1) / gran;
     if (split > tiles) split = tiles;
     QASR_HIP(hipEventRecord(fork_ev_, stream_));
     int r0 = 0;
     for (int i = 0; i < split; ++i) {
         const int t = tiles / split + (i < tiles % split ? 1 : 0);
-        const int nr = std::min(B - r0, t * 16);
+        const int nr = std::min(B - r0, t * gran);
         hipStream_t s = i == 0 ? stream_ : side_[i - 1];
         if (i > 0) QASR_HIP(hipStreamWaitEvent(s, fork_ev_, 0));
         run_decode_step(false, true, r0, nr, s);
