@@ -152,6 +152,10 @@ def main():
         audio_s = world * B * args.seconds * args.steps
         ms_step = dt / args.steps * 1e3
         dom_ms, dom_bytes = probe["layer_gemv"]
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")
+        if os.path.exists(pmc_path):       # measured in separate rocprofv3 --pmc passes of this same command
+            traffic = json.load(open(pmc_path)).get("layer_gemv_group_bytes")
         out = {
             "metric": "audio-seconds/sec (RTF^-1) Qwen3-ASR-0.6B, 30 s@16 kHz, b=32 per GPU",
             "value": round(audio_s / dt, 1),
@@ -170,9 +174,11 @@ def main():
                          "prompt_pass": round(stage_ms[2], 3), "decode": round(stage_ms[3], 3),
                          "decode_steps": steps_done},
             "pcie_inclusive_value": round(world * B * args.seconds / (ms_step / 1e3 + h2d_s), 1),
-            "roofline": {"bound": "hbm", "kernel": "decode_gemv_kernel (the four weight-streaming launches of one decoder layer)",
+            "roofline": {"bound": "hbm", "kernel": "decode_gemv2_kernel: the four weight-streaming launches of one decoder layer (qkv, o_proj, gate/up, down) "
+                                   "at the step's row-group shape",
                          "achieved": round(dom_bytes / dom_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/r01_v3_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
                          "bytes_per_launch_group": dom_bytes, "avg_ms_per_launch_group": round(dom_ms, 5),
                          "other": {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)}
                                    for k, v in probe.items()}},

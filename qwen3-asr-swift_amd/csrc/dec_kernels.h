@@ -36,7 +36,7 @@ struct KVLayout {          // one layer's cache: K/V [slot][kv_head][max_ctx][hd
 void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads,
                          int hd, const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
                          const float* rope_sin, bf16_t* qr, KVLayout cache, bf16_t* vt, int vt_stride,
-                         hipStream_t s);
+                         const int* cu, const int* slot_of_clip, int n_clips, int max_len, hipStream_t s);
 
 // Causal flash attention over packed prompts.  clip c occupies packed rows [cu[c], cu[c+1]).
 // Online softmax in key tiles of 64 with unnormalised P rounded to bf16 (restated in

@@ -91,57 +91,106 @@ __device__ __forceinline__ void norm_rope_pair(float x1, float x2, float w1, flo
     o2 = bf16_round(y1 * sn + y2 * c);
 }
 
+// HPW = 256 / HD heads per wavefront; a head lives on HD/4 lanes, lane j of a head owns elements
+// (2j, 2j+1) of the first half and the matching pair of the second half (4-byte accesses).
+template <int HD>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ slot,
                                                            const int* __restrict__ pos, int n_pos, int heads,
-                                                           int kv_heads, int hd, const bf16_t* __restrict__ qn_w,
+                                                           int kv_heads, const bf16_t* __restrict__ qn_w,
                                                            const bf16_t* __restrict__ kn_w, float eps,
                                                            const float* __restrict__ rope_cos,
                                                            const float* __restrict__ rope_sin, bf16_t* __restrict__ qr,
-                                                           KVLayout cache, bf16_t* __restrict__ vt, int vt_stride) {
+                                                           KVLayout cache) {
+    constexpr int LPH = HD / 4, HPW = 64 / LPH, HALF = HD / 2;
     const int nh = heads + 2 * kv_heads;
+    const int groups = nh / HPW;                        // head groups per position
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (wid >= (long)n_pos * nh) return;
-    const int p = (int)(wid / nh), h = (int)(wid - (long)p * nh);
-    const int half = hd / 2;
-    const bf16_t* src = qkv + (long)p * nh * hd + (long)h * hd;
+    if (wid >= (long)n_pos * groups) return;
+    const int p = (int)(wid / groups), h = (int)(wid - (long)p * groups) * HPW + lane / LPH;
+    const int j = lane % LPH;
+    const bf16_t* src = qkv + (long)p * nh * HD + (long)h * HD;
     const int sl = slot[p], ps = pos[p];
-    const bool act = lane < half;
-    if (h >= heads + kv_heads) {                      // V: plain copy into both layouts
-        const int kvh = h - heads - kv_heads;
-        if (act) {
-            bf16_t a = src[lane], b = src[lane + half];
-            bf16_t* dv = cache.v + cache.off(sl, kvh, ps);
-            dv[lane] = a;
-            dv[lane + half] = b;
-            if (vt) {
-                bf16_t* t = vt + ((long)sl * kv_heads + kvh) * hd * vt_stride + ps;
-                t[(long)lane * vt_stride] = a;
-                t[(long)(lane + half) * vt_stride] = b;
-            }
-        }
+    const unsigned a = *reinterpret_cast<const unsigned*>(src + 2 * j);
+    const unsigned bb = *reinterpret_cast<const unsigned*>(src + HALF + 2 * j);
+    if (h >= heads + kv_heads) {                        // V: plain copy (the transposed image is built separately)
+        bf16_t* dv = cache.v + cache.off(sl, h - heads - kv_heads, ps);
+        *reinterpret_cast<unsigned*>(dv + 2 * j) = a;
+        *reinterpret_cast<unsigned*>(dv + HALF + 2 * j) = bb;
         return;
     }
-    float x1 = act ? bf16_to_f32(src[lane]) : 0.0f, x2 = act ? bf16_to_f32(src[lane + half]) : 0.0f;
-    const float inv = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)hd + eps);
-    if (!act) return;
+    const float x1a = bf16_to_f32((bf16_t)(a & 0xffff)), x1b = bf16_to_f32((bf16_t)(a >> 16));
+    const float x2a = bf16_to_f32((bf16_t)(bb & 0xffff)), x2b = bf16_to_f32((bf16_t)(bb >> 16));
+    float ss = (x1a * x1a + x1b * x1b) + (x2a * x2a + x2b * x2b);
+#pragma unroll
+    for (int ofs = 1; ofs < LPH; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+    const float inv = rsqrtf(ss / (float)HD + eps);
     const bf16_t* nw = h < heads ? qn_w : kn_w;
-    float c = rope_cos[(long)ps * half + lane], sn = rope_sin[(long)ps * half + lane];
-    float o1, o2;
-    norm_rope_pair(x1, x2, bf16_to_f32(nw[lane]), bf16_to_f32(nw[lane + half]), inv, c, sn, o1, o2);
-    bf16_t* dst = h < heads ? qr + ((long)p * heads + h) * hd : cache.k + cache.off(sl, h - heads, ps);
-    dst[lane] = f32_to_bf16(o1);
-    dst[lane + half] = f32_to_bf16(o2);
+    const unsigned w1 = *reinterpret_cast<const unsigned*>(nw + 2 * j), w2 = *reinterpret_cast<const unsigned*>(nw + HALF + 2 * j);
+    const float2 cs = *reinterpret_cast<const float2*>(rope_cos + (long)ps * HALF + 2 * j);
+    const float2 sn = *reinterpret_cast<const float2*>(rope_sin + (long)ps * HALF + 2 * j);
+    float o1a, o2a, o1b, o2b;
+    norm_rope_pair(x1a, x2a, bf16_to_f32((bf16_t)(w1 & 0xffff)), bf16_to_f32((bf16_t)(w2 & 0xffff)), inv, cs.x, sn.x, o1a, o2a);
+    norm_rope_pair(x1b, x2b, bf16_to_f32((bf16_t)(w1 >> 16)), bf16_to_f32((bf16_t)(w2 >> 16)), inv, cs.y, sn.y, o1b, o2b);
+    bf16_t* dst = h < heads ? qr + ((long)p * heads + h) * HD : cache.k + cache.off(sl, h - heads, ps);
+    *reinterpret_cast<unsigned*>(dst + 2 * j) = (unsigned)f32_to_bf16(o1a) | ((unsigned)f32_to_bf16(o1b) << 16);
+    *reinterpret_cast<unsigned*>(dst + HALF + 2 * j) = (unsigned)f32_to_bf16(o2a) | ((unsigned)f32_to_bf16(o2b) << 16);
+}
+
+// V^T image for the prompt pass: cache.v rows [pos][HD] -> vt[slot][kvh][d][pos], 64 positions per workgroup,
+// transposed through LDS so both sides move 128-byte rows.
+template <int HD>
+__global__ __launch_bounds__(256) void v_transpose_kernel(KVLayout cache, const int* __restrict__ cu,
+                                                          const int* __restrict__ slot_of_clip,
+                                                          bf16_t* __restrict__ vt, int vt_stride) {
+    __shared__ bf16_t tile[64][HD + 2];
+    const int clip = blockIdx.z, kvh = blockIdx.y, p0 = blockIdx.x * 64;
+    const int T = cu[clip + 1] - cu[clip];
+    if (p0 >= T) return;
+    const int sl = slot_of_clip[clip], tid = threadIdx.x;
+    const bf16_t* src = cache.v + cache.off(sl, kvh, p0);
+    constexpr int CH = HD / 8;
+    for (int i = tid; i < 64 * CH; i += 256) {
+        const int r = i / CH, ch = i - r * CH;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (p0 + r < T) u = *reinterpret_cast<const uint4*>(src + (long)r * HD + ch * 8);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tile[r][ch * 8 + q] = e[q];
+    }
+    __syncthreads();
+    bf16_t* dst = vt + ((long)sl * cache.kv_heads + kvh) * HD * vt_stride + p0;
+    for (int i = tid; i < HD * 8; i += 256) {            // 8 chunks of 8 positions per d row
+        const int d = i >> 3, ch = i & 7;
+        uint4 o;
+        bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) oe[q] = tile[ch * 8 + q][d];
+        *reinterpret_cast<uint4*>(dst + (long)d * vt_stride + ch * 8) = o;
+    }
 }
 
 void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads, int hd,
                          const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
-                         const float* rope_sin, bf16_t* qr, KVLayout cache, bf16_t* vt, int vt_stride, hipStream_t s) {
+                         const float* rope_sin, bf16_t* qr, KVLayout cache, bf16_t* vt, int vt_stride, const int* cu,
+                         const int* slot_of_clip, int n_clips, int max_len, hipStream_t s) {
     if (n_pos <= 0) return;
-    if (hd > 128 || hd % 2) throw std::invalid_argument("head_dim must be even and <= 128");
-    long waves = (long)n_pos * (heads + 2 * kv_heads);
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
-                       kv_heads, hd, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache, vt, vt_stride);
+    const int nh = heads + 2 * kv_heads;
+    if (hd == 128 && nh % 2 == 0) {
+        long waves = (long)n_pos * (nh / 2);
+        hipLaunchKernelGGL(qk_norm_rope_kernel<128>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
+                           kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache);
+        if (vt) hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(cdiv(max_len, 64), kv_heads, n_clips), dim3(256), 0, s,
+                                   cache, cu, slot_of_clip, vt, vt_stride);
+    } else if (hd == 32 && nh % 8 == 0) {
+        long waves = (long)n_pos * (nh / 8);
+        hipLaunchKernelGGL(qk_norm_rope_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
+                           kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache);
+        if (vt) hipLaunchKernelGGL(v_transpose_kernel<32>, dim3(cdiv(max_len, 64), kv_heads, n_clips), dim3(256), 0, s,
+                                   cache, cu, slot_of_clip, vt, vt_stride);
+    } else {
+        throw std::invalid_argument("qk_norm_rope: unsupported (head_dim, head count)");
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -710,9 +759,11 @@ template <int PRO, int EPI, int NT>
 static bool gemv2_k(const DecGemv2Args& a2, hipStream_t s) {
     // (K -> waves x k-steps per wave): wide workgroups for the small-N / large-K matrices
     switch (a2.g.K) {
-        case 1024:
+        case 1024: {
+            static const int w8 = getenv("QASR_GEMV_W1024") ? atoi(getenv("QASR_GEMV_W1024")) == 8 : 1;   // A/B knob (8 waves x 4 k-steps won)
             if constexpr (EPI == DEC_EPI_LOGITS) return gemv2_nb<NT, 8, 4, PRO, EPI>(a2, s);
-            else return gemv2_nb<NT, 4, 8, PRO, EPI>(a2, s);
+            else return w8 ? gemv2_nb<NT, 8, 4, PRO, EPI>(a2, s) : gemv2_nb<NT, 4, 8, PRO, EPI>(a2, s);
+        }
         case 2048: return gemv2_nb<NT, 8, 8, PRO, EPI>(a2, s);
         case 3072:            // K = intermediate size: never behind a norm
             if constexpr (PRO == DEC_PRO_COPY) return gemv2_nb<NT, 8, 12, PRO, EPI>(a2, s);
@@ -756,10 +807,7 @@ int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* nor
 // every lane keeps an online-softmax state for the rows of its slot and its 8 head dims; the states
 // are merged across slots (shuffles) and waves (LDS) at the end.  Softmax stays in f32.
 // ------------------------------------------------------------------------------------------------
-constexpr int DA_WAVES = 8;
-constexpr int DA_MAXREP = 4;
-
-template <int HD, int REP, int DA_UNR>
+template <int HD, int REP, int DA_UNR, int DA_WAVES>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
     const bf16_t* __restrict__ qkv, const int* __restrict__ ctx_len, int heads, int kv_heads,
     const bf16_t* __restrict__ qn_w, const bf16_t* __restrict__ kn_w, float eps, const float* __restrict__ rope_cos,
@@ -772,6 +820,23 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
     __shared__ float s_o[DA_WAVES][REP][HD];
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane % CPR, slot = lane / CPR;
+    const bf16_t* kb = cache.k + cache.off(b, kvh, 0) + c * 8;
+    const bf16_t* vb = cache.v + cache.off(b, kvh, 0) + c * 8;
+    // ---- phase 0: the first DA_UNR row groups of every wave go in flight before anything else.  They need
+    // no position (rows are clamped to the allocation and masked later), so the HBM latency of the first
+    // groups hides the dependent loads of phase 1 (ctx_len -> rope table, qkv row, norm weights).
+    uint4 ku[DA_UNR], vu[DA_UNR];
+    auto issue = [&](int g0) {
+#pragma unroll
+        for (int u = 0; u < DA_UNR; ++u) {
+            int key = (g0 + u * DA_WAVES) * KPI + slot;
+            key = key < cache.max_ctx ? key : cache.max_ctx - 1;
+            ku[u] = *reinterpret_cast<const uint4*>(kb + (long)key * HD);
+            vu[u] = *reinterpret_cast<const uint4*>(vb + (long)key * HD);
+        }
+    };
+    issue(wave);
     const int pos = ctx_len[b];
     const int nh = heads + 2 * kv_heads;
     const bf16_t* row = qkv + (long)b * nh * HD;
@@ -809,7 +874,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
     }
     __syncthreads();
     // ---- phase 2: cached rows [0, pos) from HBM, the new row from LDS ----------------------------------
-    const int c = lane % CPR, slot = lane / CPR;
     float q[REP][8];
 #pragma unroll
     for (int r = 0; r < REP; ++r)
@@ -823,8 +887,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[r][j] = 0.0f;
     }
-    const bf16_t* kb = cache.k + cache.off(b, kvh, 0) + c * 8;
-    const bf16_t* vb = cache.v + cache.off(b, kvh, 0) + c * 8;
     auto absorb = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
@@ -845,27 +907,17 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
     };
     const int ngroups = (pos + KPI - 1) / KPI;
     for (int g0 = wave; g0 < ngroups; g0 += DA_WAVES * DA_UNR) {
-        uint4 ku[DA_UNR], vu[DA_UNR];
-        bool valid[DA_UNR];
+        if (g0 != wave) issue(g0);                                  // the first groups are already in flight
 #pragma unroll
         for (int u = 0; u < DA_UNR; ++u) {
-            // unconditional loads from a clamped row: a load inside `if (valid)` makes hipcc branch around it
-            // and drain vmcnt per element, which serialises the whole unrolled group
-            const int key = (g0 + u * DA_WAVES) * KPI + slot;
-            valid[u] = key < pos;
-            const int kc = valid[u] ? key : 0;
-            ku[u] = *reinterpret_cast<const uint4*>(kb + (long)kc * HD);
-            vu[u] = *reinterpret_cast<const uint4*>(vb + (long)kc * HD);
-        }
-#pragma unroll
-        for (int u = 0; u < DA_UNR; ++u) {
-            if (g0 + u * DA_WAVES < ngroups) {                     // wave-uniform
+            if (g0 + u * DA_WAVES < ngroups) {                      // wave-uniform
+                const bool valid = (g0 + u * DA_WAVES) * KPI + slot < pos;
                 float kf[8], vf[8];
                 const bf16_t* ke = reinterpret_cast<const bf16_t*>(&ku[u]);
                 const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vu[u]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { kf[j] = bf16_to_f32(ke[j]); vf[j] = bf16_to_f32(ve[j]); }
-                absorb(kf, vf, valid[u]);
+                absorb(kf, vf, valid);
             }
         }
     }
@@ -922,21 +974,21 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     if (B <= 0) return;
     const int rep = heads / kv_heads;
     const float scale = 1.0f / sqrtf((float)hd);
-    dim3 grid(kv_heads, B), block(DA_WAVES * 64);
-    static const int unr = getenv("QASR_DA_UNR") ? atoi(getenv("QASR_DA_UNR")) : 4;   // tuning knob (A/B)
-    if (hd == 128 && rep == 2 && unr == 1)
-        hipLaunchKernelGGL((decode_attention_kernel<128, 2, 1>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
-                           eps, rope_cos, rope_sin, cache, out, scale);
-    else if (hd == 128 && rep == 2 && unr == 2)
-        hipLaunchKernelGGL((decode_attention_kernel<128, 2, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
-                           eps, rope_cos, rope_sin, cache, out, scale);
-    else if (hd == 128 && rep == 2)
-        hipLaunchKernelGGL((decode_attention_kernel<128, 2, 4>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
-                           eps, rope_cos, rope_sin, cache, out, scale);
-    else if (hd == 32 && rep == 2)
-        hipLaunchKernelGGL((decode_attention_kernel<32, 2, 2>), grid, block, 0, s, qkv, ctx_len, heads, kv_heads, qn_w, kn_w,
-                           eps, rope_cos, rope_sin, cache, out, scale);
-    else
+    dim3 grid(kv_heads, B);
+    static const int unr = getenv("QASR_DA_UNR") ? atoi(getenv("QASR_DA_UNR")) : 2;      // tuning knobs (A/B)
+    static const int nw = getenv("QASR_DA_WAVES") ? atoi(getenv("QASR_DA_WAVES")) : 16;
+#define QASR_DA_GO(HD_, UNR_, W_)                                                                                   \
+    hipLaunchKernelGGL((decode_attention_kernel<HD_, 2, UNR_, W_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, \
+                       kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale)
+    if (hd == 128 && rep == 2) {
+        if (nw == 16 && unr == 2) QASR_DA_GO(128, 2, 16);
+        else if (nw == 16) QASR_DA_GO(128, 4, 16);
+        else if (unr == 1) QASR_DA_GO(128, 1, 8);
+        else if (unr == 2) QASR_DA_GO(128, 2, 8);
+        else QASR_DA_GO(128, 4, 8);
+    } else if (hd == 32 && rep == 2) {
+        QASR_DA_GO(32, 2, 8);
+    } else
         throw std::invalid_argument("decode attention: unsupported (head_dim, heads/kv_heads)");
 }
 

@@ -244,7 +244,8 @@ void Engine::run_prefill(bool want_logits) {
         rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
         gemm_nt(ADense{h, H, P, H}, L.wqkv, H, P, nh * hd, H, EpiBiasActBf16<0>{qkv, (long)nh * hd, nullptr}, s);
         qk_norm_rope_launch(qkv, d_p_slot_, d_p_pos_, P, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
-                            d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), qr, kv, d_vt_.as<bf16_t>(), vt_stride_, s);
+                            d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), qr, kv, d_vt_.as<bf16_t>(), vt_stride_,
+                            d_p_cu_, d_p_slotclip_, batch_, max_len_, s);
         prefill_attention_launch(qr, kv, d_vt_.as<bf16_t>(), vt_stride_, d_p_cu_, d_p_slotclip_, batch_, max_len_,
                                  cfg_.heads, at, s);
         gemm_nt(ADense{at, nq, P, nq}, L.wo, nq, P, H, nq, EpiResidBf16{x, H}, s);
@@ -304,9 +305,29 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
 // matrix per launch cannot fill the chip), so independent row groups issued on parallel branches overlap
 // one group's weight streaming with another's attention; the second reader of a layer's weights is served
 // from the Infinity Cache.
+static int decode_split_env() {
+    static const int v = getenv("QASR_DECODE_SPLIT") ? atoi(getenv("QASR_DECODE_SPLIT")) : 2;
+    return v;
+}
+static int decode_gran_env() {
+    static const int v = getenv("QASR_DECODE_GRAN") ? atoi(getenv("QASR_DECODE_GRAN")) : 16;
+    return v;
+}
+
+// rows of the first (largest) row group of a step
+int Engine::decode_group_rows() const {
+    const int B = batch_, gran = decode_gran_env();
+    int split = std::min(decode_split_env(), 4);
+    if (split <= 1 || B < 2 * gran) return B;
+    const int tiles = (B + gran - 1) / gran;
+    split = std::min(split, tiles);
+    const int t = tiles / split + (tiles % split ? 1 : 0);
+    return std::min(B, t * gran);
+}
+
 void Engine::issue_decode_step(int split) {
     const int B = batch_;
-    static const int gran = getenv("QASR_DECODE_GRAN") ? atoi(getenv("QASR_DECODE_GRAN")) : 16;
+    const int gran = decode_gran_env();
     if (split <= 1 || B < 2 * gran) {
         run_decode_step(false, true, 0, B, stream_);
         return;
@@ -338,8 +359,7 @@ void Engine::issue_decode_step(int split) {
 void Engine::decode_loop() {
     const int max_steps = cur_max_tokens_ - 1;
     if (max_steps <= 0) return;
-    static const int split_env = getenv("QASR_DECODE_SPLIT") ? atoi(getenv("QASR_DECODE_SPLIT")) : 2;
-    const int split = split_env;
+    const int split = decode_split_env();
     const long key = ((long)batch_ << 32) | ((long)split << 24) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
     if (use_graph_ && (graph_exec_ == nullptr || graph_key_ != key)) {
         if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
@@ -435,9 +455,11 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     hipStream_t s = stream_;
     std::vector<int> ctx(batch_);
     QASR_HIP(hipMemcpy(ctx.data(), gstate_.ctx_len, batch_ * sizeof(int), hipMemcpyDeviceToHost));
+    // same launch shape as the captured step: one row group of the batch (see issue_decode_step)
+    const int rows = decode_group_rows();
     auto body = [&]() {
         DecGemvArgs a{};
-        a.B = batch_;
+        a.B = rows;
         if (which == 0) {
             // the same four launches as run_decode_step (residual epilogues write a scratch row block)
             a.W = L.wqkv; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
@@ -449,7 +471,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             a.W = L.wdown; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
             decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
         } else if (which == 1) {
-            decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, batch_, cfg_.heads, cfg_.kv_heads, hd, L.qn,
+            decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn,
                                     L.kn, cfg_.rms_eps, d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv,
                                     d_dattn_.as<bf16_t>(), s);
         } else {
@@ -471,7 +493,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     *avg_ms = ms / (float)reps;
     double bytes = 0;
     if (which == 0) bytes = 2.0 * ((double)nh * hd * H + (double)H * nq + 2.0 * I * H + (double)H * I);
-    else if (which == 1) { for (int c : ctx) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)c; }
+    else if (which == 1) { for (int b = 0; b < rows; ++b) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)ctx[b]; }
     else bytes = 2.0 * (double)cfg_.vocab * H;
     *bytes_per_launch = bytes;
 }

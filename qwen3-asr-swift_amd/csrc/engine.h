@@ -126,6 +126,7 @@ private:
     void run_prefill(bool want_logits);
     void run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s);
     void issue_decode_step(int split);
+    int decode_group_rows() const;
     GreedyState greedy_rows(int r0) const;
     void run_lm_head(bool want_logits, int r0, int nr, hipStream_t s);
     void reset_greedy_state(int max_tokens, bool ignore_eos);
