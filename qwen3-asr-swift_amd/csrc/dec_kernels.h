@@ -50,6 +50,7 @@ enum DecEpi { DEC_EPI_BF16 = 0, DEC_EPI_RESID = 1, DEC_EPI_SWIGLU = 2, DEC_EPI_L
 
 struct DecGemvArgs {
     const bf16_t* W;       // [N][K] row-major
+    const bf16_t* Wp;      // same weight, fragment-major (pack_mfma_a_launch) for the tuned kernels; may be null
     const bf16_t* X;       // [B][K] bf16 activations
     int B, N, K;
     bf16_t* out;           // BF16: [B][N]; RESID: x in place [B][N]; SWIGLU: [B][N/2]
@@ -65,6 +66,15 @@ int decode_gemv_blocks(DecEpi epi, int N);
 // out = epi( rmsnorm(X) . W^T ).  `norm_scratch` [B][K] is only used by the generic fallback.
 int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* norm_w, float eps, bf16_t* norm_scratch,
                              hipStream_t s);
+
+// Final RMSNorm + tied LM head + argmax partials (persistent kernel where the shape allows, else the fused
+// GEMV).  lm_head_parts = partials per row the launch will produce (fixed per (N, K)); partial layout
+// [row][parts].  NOTE: the persistent form needs every row group of a step to use the same `parts`.
+int lm_head_parts(int N, int K);
+int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf16_t* norm_w, float eps, int B, int N, int K,
+                   float* logits, float* part_val, int* part_idx, bf16_t* norm_scratch, hipStream_t s);
+// Fragment-major repack of a row-major [N][K] weight (MFMA 16x16x32 A operand, 1 KiB per (row tile, k-step))
+void pack_mfma_a_launch(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s);
 
 // One new token per batch row: q/k norm + RoPE at pos = ctx_len[b], append K/V to the cache,
 // attention of the rep = heads/kv_heads query heads over the cache (f32 softmax), out [B][heads*hd].
@@ -85,6 +95,7 @@ struct GreedyState {
     int max_tokens;     // cap for this batch
     int eos;
     int ignore_eos;
+    int vocab;          // ids outside [0, vocab) (all-NaN logits) are clamped to 0: the gather must never fault
 };
 void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
                             int advance_ctx, const bf16_t* embed, bf16_t* x, int H, hipStream_t s);

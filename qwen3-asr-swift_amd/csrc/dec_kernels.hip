@@ -583,9 +583,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     uint4 w[NT][KSW];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const bf16_t* wp = a.W + (long)(n0 + t * 16 + fr) * K + fc * 8;
+        // fragment-major packed weights: block (row tile, k-step) = 1 KiB, lane-major -> every wave
+        // instruction reads 1 KiB contiguous (see pack_mfma_a_kernel)
+        const bf16_t* wp = a.Wp + ((long)(n0 / 16 + t) * (K / 32)) * 512 + lane * 8;
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) w[t][i] = *reinterpret_cast<const uint4*>(wp + (wave + WAVES * i) * 32);
+        for (int i = 0; i < KSW; ++i) w[t][i] = *reinterpret_cast<const uint4*>(wp + (long)(wave + WAVES * i) * 512);
     }
     uint2 rsd[NT][NB];
     if constexpr (EPI == DEC_EPI_RESID) {
@@ -673,6 +675,26 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
                 acc[t][b] += *reinterpret_cast<const f32x4*>(&s_red[((size_t)wv * NT * NB + t * NB + b) * 256 + lane * 4]);
     if constexpr (EPI == DEC_EPI_RESID) dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc, rsd);
     else dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc);
+}
+
+// Fragment-major repack of a row-major [N][K] weight for v_mfma_f32_16x16x32_bf16 A operands:
+// dst[((tile * K/32 + kstep) * 64 + lane) * 8 + j] = src[tile*16 + (lane & 15)][kstep*32 + (lane >> 4)*8 + j]
+__global__ void pack_mfma_a_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K) {
+    const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte chunk per thread
+    const long total = (long)N * K / 8;
+    if (chunk >= total) return;
+    const int lane = (int)(chunk & 63);
+    const long blk = chunk >> 6;
+    const int ks = (int)(blk % (K / 32));
+    const long tile = blk / (K / 32);
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (tile * 16 + (lane & 15)) * K + ks * 32 + (lane >> 4) * 8);
+    reinterpret_cast<uint4*>(dst)[chunk] = v;
+}
+
+void pack_mfma_a_launch(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s) {
+    if (N % 16 != 0 || K % 32 != 0) throw std::invalid_argument("pack: N must be a multiple of 16 and K of 32");
+    const long total = (long)N * K / 8;
+    hipLaunchKernelGGL(pack_mfma_a_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, src, dst, N, K);
 }
 
 static int dec_nt(DecEpi epi, int N) {
@@ -780,7 +802,7 @@ int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* nor
     const int nt = dec_nt(epi, a.N);
     DecGemv2Args a2{a, norm_w, eps};
     bool ok = false;
-    if (a.N % (16 * nt) == 0 && a.B <= 64) {
+    if (a.Wp && a.N % (16 * nt) == 0 && a.B <= 64) {
         if (norm_w) {
             if (epi == DEC_EPI_BF16) ok = gemv2_k<DEC_PRO_RMSNORM, DEC_EPI_BF16, 1>(a2, s);
             else if (epi == DEC_EPI_SWIGLU) ok = gemv2_k<DEC_PRO_RMSNORM, DEC_EPI_SWIGLU, 2>(a2, s);
@@ -797,6 +819,196 @@ int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* nor
         g.X = norm_scratch;
     }
     return decode_gemv_generic(epi, g, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LM head (tied embedding, N = vocab): persistent form.  The batch rows are normalised (final RMSNorm)
+// and staged into LDS ONCE per workgroup; every wave then walks its own 16-row weight tiles over the
+// full K with a two-deep register pipeline (16 k-steps = 16 KB per buffer in flight per wave), so
+// there is no cross-wave reduction and no barrier after the staging.  Each wave keeps a running
+// (max, lowest index) per batch row over bf16-rounded logits; the workgroup publishes one partial.
+// ------------------------------------------------------------------------------------------------
+constexpr int LMH_WAVES = 8, LMH_CH = 16;     // waves per workgroup, k-steps per register buffer
+
+struct LmHeadArgs {
+    const bf16_t* W;        // fragment-major packed [N/16][K/32][64 lanes][8]
+    const bf16_t* X;        // [B][K] un-normalised hidden rows
+    const bf16_t* norm_w;   // [K]
+    float eps;
+    int B, N;
+    float* logits;          // optional [B][N]
+    float* part_val;        // [B][gridDim.x]
+    int* part_idx;
+};
+
+template <int K, int NB>
+__global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    constexpr int KCH = K / 8, XSTRIDE = 2 * K + 16, NC = K / (32 * LMH_CH);   // chunks per tile
+    constexpr int TPR = 32, XI = KCH / TPR;                                      // 16 rows per staging pass
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    char* s_x = dsm;
+    // ---- weights of the first chunk go in flight before the activation staging -------------------------
+    const int total_waves = gridDim.x * LMH_WAVES, gw = blockIdx.x * LMH_WAVES + wave;
+    const int ntiles = a.N / 16;
+    const int my_tiles = gw < ntiles ? (ntiles - gw + total_waves - 1) / total_waves : 0;
+    const int nitems = my_tiles * NC;
+    uint4 wa[LMH_CH], wb[LMH_CH];
+    auto issue = [&](uint4 (&w)[LMH_CH], int item) {
+        const int tile = gw + (item / NC) * total_waves, ch = item % NC;
+        const bf16_t* wp = a.W + ((long)tile * (K / 32) + ch * LMH_CH) * 512 + lane * 8;   // packed, see pack_mfma_a_kernel
+#pragma unroll
+        for (int i = 0; i < LMH_CH; ++i) w[i] = *reinterpret_cast<const uint4*>(wp + i * 512);
+    };
+    if (nitems > 0) issue(wa, 0);
+    // ---- stage + RMSNorm the batch rows, 16 rows per pass (row on 32 adjacent lanes) --------------------
+    {
+        const int srow = tid / TPR, scol = tid % TPR;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int r = nb * 16 + srow;
+            const bool live = r < a.B;
+            const bf16_t* xp = a.X + (long)(live ? r : 0) * K + scol * 8;
+            uint4 xr[XI];
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
+            }
+#pragma unroll
+            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            const float inv = rsqrtf(ss / (float)K + a.eps);
+            char* xrow = s_x + (size_t)r * XSTRIDE + scol * 16;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const uint4 nw = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+                const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
+                uint4 o;
+                bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    oe[j] = live ? f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv)) : (bf16_t)0;
+                *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stream the weight tiles ---------------------------------------------------------------------------
+    f32x4 acc[NB];
+    float best[NB];
+    int bidx[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { acc[b] = f32x4{0.f, 0.f, 0.f, 0.f}; best[b] = -INFINITY; bidx[b] = 0x7fffffff; }
+    auto consume = [&](const uint4 (&w)[LMH_CH], int item) {
+        const int tile = gw + (item / NC) * total_waves, ch = item % NC;
+#pragma unroll
+        for (int i = 0; i < LMH_CH; ++i) {
+            const int kb = ((ch * LMH_CH + i) * 32 + fc * 8) * 2;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const uint4 xf = *reinterpret_cast<const uint4*>(s_x + (size_t)(b * 16 + fr) * XSTRIDE + kb);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, w[i]),
+                                                                 __builtin_bit_cast(mfma_bf16x8, xf), acc[b], 0, 0, 0);
+            }
+        }
+        if (ch == NC - 1) {                                   // tile complete: acc[b][j] = logit[b*16+fr][tile*16+fc*4+j]
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = b * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = tile * 16 + fc * 4 + j;
+                    const float v = bf16_round(acc[b][j]);
+                    if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
+                    if (v > best[b] || (v == best[b] && n < bidx[b])) { best[b] = v; bidx[b] = n; }
+                }
+                acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    for (int item = 0; item < nitems; item += 2) {
+        if (item + 1 < nitems) issue(wb, item + 1);
+        consume(wa, item);
+        if (item + 1 < nitems) {
+            if (item + 2 < nitems) issue(wa, item + 2);
+            consume(wb, item + 1);
+        }
+    }
+    // ---- argmax partial of the workgroup ---------------------------------------------------------------------
+    float* s_v = reinterpret_cast<float*>(dsm);               // the activation image is dead now
+    int* s_i = reinterpret_cast<int*>(dsm + LMH_WAVES * NB * 16 * sizeof(float));
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int ofs = 16; ofs < 64; ofs <<= 1) {
+            const float ov = __shfl_xor(best[b], ofs, 64);
+            const int oi = __shfl_xor(bidx[b], ofs, 64);
+            if (ov > best[b] || (ov == best[b] && oi < bidx[b])) { best[b] = ov; bidx[b] = oi; }
+        }
+        if (fc == 0) { s_v[(wave * NB + b) * 16 + fr] = best[b]; s_i[(wave * NB + b) * 16 + fr] = bidx[b]; }
+    }
+    __syncthreads();
+    if (tid < NB * 16 && tid < a.B) {
+        const int b = tid >> 4, r = tid & 15;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < LMH_WAVES; ++w) {
+            const float ov = s_v[(w * NB + b) * 16 + r];
+            const int oi = s_i[(w * NB + b) * 16 + r];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        a.part_val[(long)tid * gridDim.x + blockIdx.x] = bv;
+        a.part_idx[(long)tid * gridDim.x + blockIdx.x] = bi;
+    }
+}
+
+constexpr int LMH_GRID = 256;
+
+template <int K, int NB>
+static void lm_head_go(const LmHeadArgs& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)NB * 16 * (2 * K + 16);
+    auto kern = lm_head_kernel<K, NB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(LMH_GRID), dim3(LMH_WAVES * 64), lds, s, a);
+}
+
+bool lm_head_supported(int N, int K) { return (K == 1024 || K == 2048) && N % 16 == 0 && N / 16 >= LMH_GRID * LMH_WAVES; }
+int lm_head_parts(int N, int K) { return lm_head_supported(N, K) ? LMH_GRID : decode_gemv_blocks(DEC_EPI_LOGITS, N); }
+
+// final RMSNorm + tied LM head + per-workgroup argmax partials; returns the number of partials per row
+int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf16_t* norm_w, float eps, int B, int N, int K,
+                   float* logits, float* part_val, int* part_idx, bf16_t* norm_scratch, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int nb = (B + 15) / 16;
+    if (Wp && lm_head_supported(N, K) && nb <= (K == 1024 ? 4 : 2)) {
+        LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx};
+        if (K == 1024) {
+            switch (nb) {
+                case 1: lm_head_go<1024, 1>(a, s); break;
+                case 2: lm_head_go<1024, 2>(a, s); break;
+                case 3: lm_head_go<1024, 3>(a, s); break;
+                default: lm_head_go<1024, 4>(a, s); break;
+            }
+        } else {
+            if (nb == 1) lm_head_go<2048, 1>(a, s); else lm_head_go<2048, 2>(a, s);
+        }
+        return LMH_GRID;
+    }
+    if (Wp && lm_head_supported(N, K)) throw std::length_error("LM head: batch rows exceed the LDS image at this hidden size");
+    DecGemvArgs g{};
+    g.W = W; g.X = X; g.B = B; g.N = N; g.K = K; g.logits = logits; g.part_val = part_val; g.part_idx = part_idx;
+    return decode_gemv_fused_launch(DEC_EPI_LOGITS, g, norm_w, eps, norm_scratch, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -916,7 +1128,12 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
                 const bf16_t* ke = reinterpret_cast<const bf16_t*>(&ku[u]);
                 const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vu[u]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { kf[j] = bf16_to_f32(ke[j]); vf[j] = bf16_to_f32(ve[j]); }
+                // rows beyond the context were read from unwritten cache memory: zero them (p = 0 would still
+                // turn a stale NaN/Inf into NaN through 0 * x)
+                for (int j = 0; j < 8; ++j) {
+                    kf[j] = valid ? bf16_to_f32(ke[j]) : 0.0f;
+                    vf[j] = valid ? bf16_to_f32(ve[j]) : 0.0f;
+                }
                 absorb(kf, vf, valid);
             }
         }
@@ -1020,7 +1237,7 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
         }
         __syncthreads();
     }
-    const int tok = s_i[0];
+    const int tok = (unsigned)s_i[0] < (unsigned)st.vocab ? s_i[0] : 0;
     if (tid == 0) {
         if (advance_ctx) st.ctx_len[b] += 1;
         if (!st.finished[b]) {

@@ -38,11 +38,23 @@ __global__ void add_scalar_kernel(int* p, int n, int v) {
     if (i < n) p[i] += v;
 }
 
+// decode-step weights are streamed as MFMA A fragments: keep a fragment-major copy (1.19 GB extra for 0.6B)
+const bf16_t* Engine::packed_copy(const bf16_t* w, int N, int K) {
+    if (N % 16 != 0 || K % 32 != 0) return nullptr;
+    auto buf = std::make_unique<DevBuf>();
+    buf->alloc((size_t)N * K * sizeof(bf16_t));
+    pack_mfma_a_launch(w, buf->as<bf16_t>(), N, K, stream_);
+    const bf16_t* p = buf->as<bf16_t>();
+    fused_.push_back(std::move(buf));
+    return p;
+}
+
 void Engine::finalize_decoder() {
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nkv = cfg_.kv_heads * hd, I = cfg_.inter;
     if (cfg_.inter % 16 != 0 || H % 32 != 0) throw std::invalid_argument("decoder widths must be multiples of 16/32");
     decw_.embed = wptr("model.embed_tokens.weight", {cfg_.vocab, H});
     decw_.norm = wptr("model.norm.weight", {H});
+    decw_.embed_p = packed_copy(decw_.embed, cfg_.vocab, H);
     decw_.layers.clear();
     for (int i = 0; i < cfg_.dec_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
@@ -70,6 +82,10 @@ void Engine::finalize_decoder() {
         hipLaunchKernelGGL(interleave_gate_up_kernel, dim3(2 * I), dim3(128), 0, stream_, wg, wu, gu->as<bf16_t>(), I, H);
         L.wgu = gu->as<bf16_t>();
         fused_.push_back(std::move(gu));
+        L.wqkv_p = packed_copy(L.wqkv, nq + 2 * nkv, H);
+        L.wo_p = packed_copy(L.wo, H, nq);
+        L.wgu_p = packed_copy(L.wgu, 2 * I, H);
+        L.wdown_p = packed_copy(L.wdown, H, I);
         decw_.layers.push_back(L);
     }
     // capacity: prompt = 16 fixed ids + audio tokens + context/language extras (Qwen3ASR.swift:199-233)
@@ -121,9 +137,10 @@ void Engine::finalize_decoder() {
     d_dattn_.alloc((size_t)B * nq * 2);
     d_dact_.alloc((size_t)B * I * 2);
     d_logits_.alloc((size_t)B * cfg_.vocab * sizeof(float));
-    n_parts_ = decode_gemv_blocks(DEC_EPI_LOGITS, cfg_.vocab);
-    d_part_val_.alloc((size_t)B * n_parts_ * sizeof(float));
-    d_part_idx_.alloc((size_t)B * n_parts_ * sizeof(int));
+    n_parts_ = lm_head_parts(cfg_.vocab, H);
+    const int parts_cap = std::max(n_parts_, decode_gemv_blocks(DEC_EPI_LOGITS, cfg_.vocab));
+    d_part_val_.alloc((size_t)B * parts_cap * sizeof(float));
+    d_part_idx_.alloc((size_t)B * parts_cap * sizeof(int));
     const size_t pmeta = (size_t)max_pos_ * 4 * sizeof(int) + (size_t)(3 * B + 2) * sizeof(int);
     h_pmeta_.alloc(pmeta);
     d_pmeta_.alloc(pmeta);
@@ -138,6 +155,7 @@ void Engine::finalize_decoder() {
     gstate_.n_active = gstate_.ctx_len + B;
     gstate_.max_new = cfg_.max_new_tokens;
     gstate_.eos = cfg_.tok_im_end;
+    gstate_.vocab = cfg_.vocab;
     for (auto& e : ev_)
         if (!e) QASR_HIP(hipEventCreate(&e));
     if (!fork_ev_) {
@@ -223,12 +241,10 @@ void Engine::reset_greedy_state(int max_tokens, bool ignore_eos) {
 
 void Engine::run_lm_head(bool want_logits, int r0, int nr, hipStream_t s) {
     const int H = cfg_.hidden;
-    DecGemvArgs a{};
-    a.W = decw_.embed; a.X = d_dx_.as<bf16_t>() + (size_t)r0 * H; a.B = nr; a.N = cfg_.vocab; a.K = H;
-    a.logits = want_logits ? d_logits_.as<float>() + (size_t)r0 * cfg_.vocab : nullptr;
-    a.part_val = d_part_val_.as<float>() + (size_t)r0 * n_parts_;
-    a.part_idx = d_part_idx_.as<int>() + (size_t)r0 * n_parts_;
-    decode_gemv_fused_launch(DEC_EPI_LOGITS, a, decw_.norm, cfg_.rms_eps, d_dh_.as<bf16_t>() + (size_t)r0 * H, s);
+    lm_head_launch(decw_.embed, decw_.embed_p, d_dx_.as<bf16_t>() + (size_t)r0 * H, decw_.norm, cfg_.rms_eps, nr, cfg_.vocab, H,
+                   want_logits ? d_logits_.as<float>() + (size_t)r0 * cfg_.vocab : nullptr,
+                   d_part_val_.as<float>() + (size_t)r0 * n_parts_, d_part_idx_.as<int>() + (size_t)r0 * n_parts_,
+                   d_dh_.as<bf16_t>() + (size_t)r0 * H, s);
 }
 
 void Engine::run_prefill(bool want_logits) {
@@ -270,7 +286,7 @@ GreedyState Engine::greedy_rows(int r0) const {
 
 // One decode step for batch rows [r0, r0 + nr) on stream s.  Rows are independent, so a step can be
 // issued as several row groups on parallel graph branches (see decode_loop).
-void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s) {
+void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s, bool with_head) {
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
     bf16_t* x = d_dx_.as<bf16_t>() + (size_t)r0 * H;
     bf16_t* h = d_dh_.as<bf16_t>() + (size_t)r0 * H;
@@ -284,17 +300,18 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         kv.k += kv.off(r0, 0, 0);
         kv.v += kv.off(r0, 0, 0);
         DecGemvArgs a{};
-        a.W = L.wqkv; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
+        a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
         decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, h, s);
         decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
                                 d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv, at, s);
-        a.W = L.wo; a.X = at; a.N = H; a.K = nq; a.out = x;
+        a.W = L.wo; a.Wp = L.wo_p; a.X = at; a.N = H; a.K = nq; a.out = x;
         decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
-        a.W = L.wgu; a.X = x; a.N = 2 * I; a.K = H; a.out = act;
+        a.W = L.wgu; a.Wp = L.wgu_p; a.X = x; a.N = 2 * I; a.K = H; a.out = act;
         decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, h, s);
-        a.W = L.wdown; a.X = act; a.N = H; a.K = I; a.out = x;
+        a.W = L.wdown; a.Wp = L.wdown_p; a.X = act; a.N = H; a.K = I; a.out = x;
         decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
     }
+    if (!with_head) return;
     run_lm_head(want_logits, r0, nr, s);
     if (greedy)
         greedy_finalize_launch(d_part_val_.as<float>() + (size_t)r0 * n_parts_, d_part_idx_.as<int>() + (size_t)r0 * n_parts_,
@@ -329,7 +346,7 @@ void Engine::issue_decode_step(int split) {
     const int B = batch_;
     const int gran = decode_gran_env();
     if (split <= 1 || B < 2 * gran) {
-        run_decode_step(false, true, 0, B, stream_);
+        run_decode_step(false, true, 0, B, stream_, true);
         return;
     }
     if (split > 4) split = 4;
@@ -343,13 +360,17 @@ void Engine::issue_decode_step(int split) {
         const int nr = std::min(B - r0, t * gran);
         hipStream_t s = i == 0 ? stream_ : side_[i - 1];
         if (i > 0) QASR_HIP(hipStreamWaitEvent(s, fork_ev_, 0));
-        run_decode_step(false, true, r0, nr, s);
+        run_decode_step(false, true, r0, nr, s, false);           // layers only; the head runs once after the join
         if (i > 0) {
             QASR_HIP(hipEventRecord(join_ev_[i - 1], s));
             QASR_HIP(hipStreamWaitEvent(stream_, join_ev_[i - 1], 0));
         }
         r0 += nr;
     }
+    // LM head streams 311 MB of tied-embedding weights: once per step for all rows, not once per row group
+    run_lm_head(false, 0, B, stream_);
+    greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, B, 1, decw_.embed,
+                           d_dx_.as<bf16_t>(), cfg_.hidden, stream_);
 }
 
 // Greedy loop (Qwen3ASR.swift:344-389): token 0 comes from the prompt pass; every further token costs
@@ -462,22 +483,21 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         a.B = rows;
         if (which == 0) {
             // the same four launches as run_decode_step (residual epilogues write a scratch row block)
-            a.W = L.wqkv; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
+            a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
             decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
-            a.W = L.wo; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();
+            a.W = L.wo; a.Wp = L.wo_p; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();
             decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
-            a.W = L.wgu; a.X = d_dx_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
+            a.W = L.wgu; a.Wp = L.wgu_p; a.X = d_dx_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
             decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
-            a.W = L.wdown; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
+            a.W = L.wdown; a.Wp = L.wdown_p; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
             decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
         } else if (which == 1) {
             decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn,
                                     L.kn, cfg_.rms_eps, d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv,
                                     d_dattn_.as<bf16_t>(), s);
         } else {
-            a.W = decw_.embed; a.X = d_dx_.as<bf16_t>(); a.N = cfg_.vocab; a.K = H;
-            a.part_val = d_part_val_.as<float>(); a.part_idx = d_part_idx_.as<int>();
-            decode_gemv_fused_launch(DEC_EPI_LOGITS, a, decw_.norm, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
+            lm_head_launch(decw_.embed, decw_.embed_p, d_dx_.as<bf16_t>(), decw_.norm, cfg_.rms_eps, batch_, cfg_.vocab, H, nullptr,
+                           d_part_val_.as<float>(), d_part_idx_.as<int>(), d_dh_.as<bf16_t>(), s);
         }
     };
     for (int i = 0; i < 3; ++i) body();
@@ -531,7 +551,7 @@ void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
         *idx.as<int>() = tokens[i];
         QASR_HIP(hipMemcpyAsync(didx.p, idx.p, sizeof(int), hipMemcpyHostToDevice, stream_));
         gather_rows_launch(decw_.embed, didx.as<int>(), d_dx_.as<bf16_t>(), 1, cfg_.hidden, stream_);
-        run_decode_step(true, false, 0, 1, stream_);
+        run_decode_step(true, false, 0, 1, stream_, true);
         hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(64), 0, stream_, gstate_.ctx_len, 1, 1);
         QASR_HIP(hipMemcpyAsync(logits + (size_t)i * cfg_.vocab, d_logits_.p, (size_t)cfg_.vocab * sizeof(float),
                                 hipMemcpyDeviceToHost, stream_));

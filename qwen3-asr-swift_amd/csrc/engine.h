@@ -122,9 +122,10 @@ private:
     void plan_encoder();          // chunk / token / window tables of the current batch -> HBM
     void run_encoder();
     void finalize_decoder();
+    const bf16_t* packed_copy(const bf16_t* w, int N, int K);
     void plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio);
     void run_prefill(bool want_logits);
-    void run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s);
+    void run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s, bool with_head);
     void issue_decode_step(int split);
     int decode_group_rows() const;
     GreedyState greedy_rows(int r0) const;
@@ -177,9 +178,10 @@ private:
     // ---- text decoder ------------------------------------------------------------------------
     struct DecLayerW {
         const bf16_t *ln1, *wqkv, *qn, *kn, *wo, *ln2, *wgu, *wdown;
+        const bf16_t *wqkv_p, *wo_p, *wgu_p, *wdown_p;       // fragment-major copies for the decode step
     };
     struct DecW {
-        const bf16_t *embed, *norm;
+        const bf16_t *embed, *norm, *embed_p;
         std::vector<DecLayerW> layers;
     } decw_;
     int max_prompt_ = 0, max_ctx_ = 0, max_pos_ = 0, vt_stride_ = 0;

@@ -78,3 +78,22 @@ def test_batch_invariance_and_determinism(full):
         assert eng.transcribe_batch([clips[k]], max_tokens=5, ignore_eos=True)[0] == a[k]
     sub = eng.transcribe_batch(clips[5:22], max_tokens=5, ignore_eos=True)      # 17 rows, other slots
     assert sub == a[5:22]
+
+
+def test_stale_memory_does_not_leak_into_results(full):
+    """Engines recycle HBM: a second engine created after a first one has dirtied memory (NaN patterns in
+    what becomes the KV cache) must give the same tokens as a fresh one."""
+    import torch as _t
+    eng, sd = full
+    clips = [synth.synth_waveform(3, 1.0)]
+    ref = eng.transcribe_batch(clips, max_tokens=4, ignore_eos=True)
+    if _t.cuda.is_available():
+        junk = _t.full((1 << 28,), float("nan"), dtype=_t.bfloat16, device="cuda")   # 512 MB of NaNs, then freed
+        del junk
+        _t.cuda.empty_cache()
+    e2 = gpu_util.Engine("0.6B", max_batch=2, max_audio_seconds=6, max_new_tokens=32)
+    try:
+        e2.load_state_dict(sd)
+        assert e2.transcribe_batch(clips, max_tokens=4, ignore_eos=True) == ref
+    finally:
+        e2.close()
