@@ -151,11 +151,15 @@ def main():
     if rank == 0:
         audio_s = world * B * args.seconds * args.steps
         ms_step = dt / args.steps * 1e3
-        dom_ms, dom_bytes = probe["layer_gemv"]
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")
-        if os.path.exists(pmc_path):       # measured in separate rocprofv3 --pmc passes of this same command
-            traffic = json.load(open(pmc_path)).get("layer_gemv_group_bytes")
+        # dominant kernel by GPU time (profiles/r01_v4_bench_kernel_stats.csv: 32 %): decode_attention_kernel
+        dom_ms, dom_bytes = probe["decode_attn"]
+        traffic, traffic_note = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")
+        if os.path.exists(pmc_path):       # measured in separate rocprofv3 --pmc passes (see the file's "source")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("decode_attention_bytes")
+            traffic_note = ("profiles/r01_v4_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc "
+                            "passes at mean context 414 where the algorithmic bytes are 54.3e6 (ratio 1.015)")
         out = {
             "metric": "audio-seconds/sec (RTF^-1) Qwen3-ASR-0.6B, 30 s@16 kHz, b=32 per GPU",
             "value": round(audio_s / dt, 1),
@@ -174,12 +178,16 @@ def main():
                          "prompt_pass": round(stage_ms[2], 3), "decode": round(stage_ms[3], 3),
                          "decode_steps": steps_done},
             "pcie_inclusive_value": round(world * B * args.seconds / (ms_step / 1e3 + h2d_s), 1),
-            "roofline": {"bound": "hbm", "kernel": "decode_gemv2_kernel: the four weight-streaming launches of one decoder layer (qkv, o_proj, gate/up, down) "
-                                   "at the step's row-group shape",
+            "roofline": {"bound": "hbm",
+                         "kernel": "decode_attention_kernel (one launch = one decoder layer's attention for all batch rows: "
+                                   "K and V rows of every row's context are streamed once)",
                          "achieved": round(dom_bytes / dom_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "profiles/r01_v3_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
-                         "bytes_per_launch_group": dom_bytes, "avg_ms_per_launch_group": round(dom_ms, 5),
+                         "traffic_source": traffic_note,
+                         "bytes_per_launch": dom_bytes, "avg_ms_per_launch": round(dom_ms, 5),
+                         "how": "algorithmic bytes = sum_b 2 (K,V) x 8 kv heads x 128 x 2 B x ctx_b at the probe's context; duration = HIP "
+                                "events on the engine stream around each of 20 launches, each preceded by an untimed weight-streaming "
+                                "launch as in the real step (qasr_kernel_probe)",
                          "other": {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)}
                                    for k, v in probe.items()}},
         }

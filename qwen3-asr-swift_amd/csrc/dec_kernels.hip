@@ -839,6 +839,7 @@ struct LmHeadArgs {
     float* logits;          // optional [B][N]
     float* part_val;        // [B][gridDim.x]
     int* part_idx;
+    int diag;               // 1: diagnostic build of the loop without LDS reads / MFMA (wrong results, timing only)
 };
 
 template <int K, int NB>
@@ -906,6 +907,10 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
     for (int b = 0; b < NB; ++b) { acc[b] = f32x4{0.f, 0.f, 0.f, 0.f}; best[b] = -INFINITY; bidx[b] = 0x7fffffff; }
     auto consume = [&](const uint4 (&w)[LMH_CH], int item) {
         const int tile = gw + (item / NC) * total_waves, ch = item % NC;
+        if (a.diag) {
+#pragma unroll
+            for (int i = 0; i < LMH_CH; ++i) acc[0][0] += __uint_as_float(w[i].x ^ w[i].y ^ w[i].z ^ w[i].w);
+        } else
 #pragma unroll
         for (int i = 0; i < LMH_CH; ++i) {
             const int kb = ((ch * LMH_CH + i) * 32 + fc * 8) * 2;
@@ -969,6 +974,10 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
     }
 }
 
+static int lmh_grid() {
+    static const int g = getenv("QASR_LMH_GRID") ? atoi(getenv("QASR_LMH_GRID")) : 256;
+    return g;
+}
 constexpr int LMH_GRID = 256;
 
 template <int K, int NB>
@@ -980,11 +989,11 @@ static void lm_head_go(const LmHeadArgs& a, hipStream_t s) {
         QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(LMH_GRID), dim3(LMH_WAVES * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(lmh_grid()), dim3(LMH_WAVES * 64), lds, s, a);
 }
 
-bool lm_head_supported(int N, int K) { return (K == 1024 || K == 2048) && N % 16 == 0 && N / 16 >= LMH_GRID * LMH_WAVES; }
-int lm_head_parts(int N, int K) { return lm_head_supported(N, K) ? LMH_GRID : decode_gemv_blocks(DEC_EPI_LOGITS, N); }
+bool lm_head_supported(int N, int K) { return (K == 1024 || K == 2048) && N % 16 == 0 && N / 16 >= 512 * LMH_WAVES; }
+int lm_head_parts(int N, int K) { return lm_head_supported(N, K) ? lmh_grid() : decode_gemv_blocks(DEC_EPI_LOGITS, N); }
 
 // final RMSNorm + tied LM head + per-workgroup argmax partials; returns the number of partials per row
 int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf16_t* norm_w, float eps, int B, int N, int K,
@@ -992,7 +1001,8 @@ int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf1
     if (B <= 0) return 0;
     const int nb = (B + 15) / 16;
     if (Wp && lm_head_supported(N, K) && nb <= (K == 1024 ? 4 : 2)) {
-        LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx};
+        static const int diag = getenv("QASR_LMH_DIAG") ? atoi(getenv("QASR_LMH_DIAG")) : 0;
+        LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx, diag};
         if (K == 1024) {
             switch (nb) {
                 case 1: lm_head_go<1024, 1>(a, s); break;
@@ -1003,7 +1013,7 @@ int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf1
         } else {
             if (nb == 1) lm_head_go<2048, 1>(a, s); else lm_head_go<2048, 2>(a, s);
         }
-        return LMH_GRID;
+        return lmh_grid();
     }
     if (Wp && lm_head_supported(N, K)) throw std::length_error("LM head: batch rows exceed the LDS image at this hidden size");
     DecGemvArgs g{};

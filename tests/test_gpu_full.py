@@ -97,3 +97,33 @@ def test_stale_memory_does_not_leak_into_results(full):
         assert e2.transcribe_batch(clips, max_tokens=4, ignore_eos=True) == ref
     finally:
         e2.close()
+
+
+def test_30s_clips_batch8_properties():
+    """configs[1] shape (8 x 30 s, full geometry): size-independent properties -- every clip yields exactly
+    max_tokens ids in range, results are deterministic, independent of batch composition (B=8 vs B=1 vs a
+    permuted batch) and identical through the row-group-split decode graph (QASR_DECODE_SPLIT is a launch-time
+    partition of independent rows)."""
+    sd = synth.synth_state_dict(C.AUDIO_SMALL, C.TEXT_SMALL, seed=0, init="hf")
+    eng = gpu_util.Engine("0.6B", max_batch=8, max_audio_seconds=30, max_new_tokens=64)
+    try:
+        eng.load_state_dict(sd)
+        clips = [synth.synth_waveform(k, 30.0) for k in range(8)]
+        a = eng.transcribe_batch(clips, max_tokens=12, ignore_eos=True)
+        assert all(len(t) == 12 and all(0 <= x < C.TEXT_SMALL.vocab for x in t) for t in a)
+        assert eng.transcribe_batch(clips, max_tokens=12, ignore_eos=True) == a
+        perm = [5, 2, 7, 0, 3, 6, 1, 4]
+        b = eng.transcribe_batch([clips[i] for i in perm], max_tokens=12, ignore_eos=True)
+        assert [b[perm.index(i)] for i in range(8)] == a
+        assert eng.transcribe_batch([clips[3]], max_tokens=12, ignore_eos=True)[0] == a[3]
+        # ragged: a 30 s clip next to very short ones
+        mix = [clips[0], synth.synth_waveform(9, 0.3), clips[1][:100000], synth.synth_waveform(10, 12.34)]
+        m = eng.transcribe_batch(mix, max_tokens=12, ignore_eos=True)
+        assert m[0] == a[0]
+        for i in (1, 2, 3):
+            assert eng.transcribe_batch([mix[i]], max_tokens=12, ignore_eos=True)[0] == m[i]
+        mel = eng.mel(clips[2])
+        assert mel.shape == (128, 3000) and np.isfinite(mel).all()
+        assert eng.encode(mel).shape == (390, 1024)
+    finally:
+        eng.close()
