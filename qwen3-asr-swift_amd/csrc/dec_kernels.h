@@ -76,7 +76,8 @@ int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf1
 // Fragment-major repack of a row-major [N][K] weight (MFMA 16x16x32 A operand, 1 KiB per (row tile, k-step))
 void pack_mfma_a_launch(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_t s);
 
-// One new token per batch row: q/k norm + RoPE at pos = ctx_len[b], append K/V to the cache,
+// One new token per batch row: q/k norm + RoPE at pos = ctx_len[b] (rope_cos/rope_sin are the per-row
+// RopeRows of that position), append K/V to the cache,
 // attention of the rep = heads/kv_heads query heads over the cache (f32 softmax), out [B][heads*hd].
 void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int heads, int kv_heads, int hd,
                              const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
@@ -97,8 +98,15 @@ struct GreedyState {
     int ignore_eos;
     int vocab;          // ids outside [0, vocab) (all-NaN logits) are clamped to 0: the gather must never fault
 };
+// rope rows of the next decode position, one per batch row (cos_rows/sin_rows [B][half]), copied from the
+// position-indexed tables by greedy_finalize so decode attention does not chain ctx_len -> table lookup
+struct RopeRows {
+    const float* cos_table; const float* sin_table;
+    float* cos_rows; float* sin_rows;
+    int half;
+};
 void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
-                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, hipStream_t s);
+                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, RopeRows rr, hipStream_t s);
 
 // ---- epilogues for the prefill GEMMs ----------------------------------------------------------------
 // x_bf16[m][n] = bf16(x + bf16(acc))   (residual add in the decoder dtype)

@@ -199,7 +199,7 @@ void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int
 // an XOR chunk swizzle, S = Q K^T (16x16x32 MFMA), online softmax on the accumulator layout (a row
 // lives on 16 lanes), P -> bf16 through a wave-private LDS image -> A operand of P V.
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, int MT>
 __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __restrict__ qr, KVLayout cache,
                                                                 const bf16_t* __restrict__ vt, int vt_stride,
                                                                 const int* __restrict__ cu,
@@ -210,10 +210,16 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
     constexpr int KS = HD / 32;            // k-steps of Q K^T
     constexpr int DT = HD / 16;            // output d tiles
     constexpr int PLD = KT + 8;
-    __shared__ __attribute__((aligned(16))) bf16_t s_k[KT * HD];
-    __shared__ __attribute__((aligned(16))) bf16_t s_v[HD * KT];
-    __shared__ __attribute__((aligned(16))) bf16_t s_p[4][32][PLD];
-    const int clip = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    constexpr int NKL = KT * KCH / 256;    // K-tile chunks staged per thread
+    constexpr int NVL = HD * (KT / 8) / 256;   // V^T-tile chunks staged per thread
+    static_assert(KT * KCH % 256 == 0 && HD * (KT / 8) % 256 == 0, "tile staging must divide evenly");
+    // one LDS block: K tile | V^T tile (re-used as the output staging image at the end) | P images
+    __shared__ __attribute__((aligned(16))) bf16_t s_kv[2 * KT * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t s_p[4][16 * MT][PLD];
+    bf16_t* s_k = s_kv;
+    bf16_t* s_v = s_kv + KT * HD;
+    constexpr int QW = 16 * MT, QB = 4 * QW;   // query rows per wave / per workgroup
+    const int clip = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
     const int row0 = cu[clip], T = cu[clip + 1] - row0;
     if (q0 >= T) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
@@ -221,50 +227,68 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
     const int kvh = h / (heads / cache.kv_heads);
     const bf16_t* kbase = cache.k + cache.off(sl, kvh, 0);
     const bf16_t* vbase = vt + ((long)sl * cache.kv_heads + kvh) * HD * vt_stride;
-    const int qw = q0 + wave * 32;         // first query row of this wave
+    const int qw = q0 + wave * QW;         // first query row of this wave
 
-    mfma_bf16x8 qf[2][KS];
+    // tile staging global -> registers -> LDS inside the tile step (a register prefetch of tile kt+1 across the
+    // MFMAs costs 32 more VGPRs, which drops this kernel from 2 waves/SIMD to 1 with spills: measured slower)
+    auto stage = [&](int k0) {
+        uint4 kreg[NKL], vreg[NVL];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = tid + i * 256, key = idx / KCH, ch = idx - key * KCH;
+            const int kc = k0 + key < T ? k0 + key : T - 1;              // clamped row, zeroed below
+            kreg[i] = *reinterpret_cast<const uint4*>(kbase + (long)kc * HD + ch * 8);
+            if (k0 + key >= T) kreg[i] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int idx = tid + i * 256, d = idx / (KT / 8), ch = idx - d * (KT / 8);
+            vreg[i] = *reinterpret_cast<const uint4*>(vbase + (long)d * vt_stride + k0 + ch * 8);   // V^T is zero past T
+        }
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = tid + i * 256, key = idx / KCH, ch = idx - key * KCH;
+            *reinterpret_cast<uint4*>(&s_k[key * HD + ((ch ^ (key & (KCH - 1))) << 3)]) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int idx = tid + i * 256, d = idx / (KT / 8), ch = idx - d * (KT / 8);
+            *reinterpret_cast<uint4*>(&s_v[d * KT + ((ch ^ (d & 7)) << 3)]) = vreg[i];
+        }
+    };
+
+    mfma_bf16x8 qf[MT][KS];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
         const int r = qw + mi * 16 + fr;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (r < T) u = *reinterpret_cast<const uint4*>(qr + ((long)(row0 + r) * heads + h) * HD + s * 32 + fc * 8);
+            const int rc = r < T ? r : T - 1;
+            uint4 u = *reinterpret_cast<const uint4*>(qr + ((long)(row0 + rc) * heads + h) * HD + s * 32 + fc * 8);
+            if (r >= T) u = make_uint4(0, 0, 0, 0);
             qf[mi][s] = __builtin_bit_cast(mfma_bf16x8, u);
         }
     }
-    f32x4 o[2][DT];
+    f32x4 o[MT][DT];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int d = 0; d < DT; ++d) o[mi][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[2][4], l_run[2][4];
+    float m_run[MT][4], l_run[MT][4];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { m_run[mi][j] = -INFINITY; l_run[mi][j] = 0.0f; }
 
-    const int q_hi = min(q0 + 128, T);                 // causal: keys < q_hi
+    const int q_hi = min(q0 + QB, T);                 // causal: keys < q_hi
     const int n_tiles = (q_hi + KT - 1) / KT;
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int k0 = kt * KT;
-        __syncthreads();                               // previous tile's reads are done
-        for (int i = tid; i < KT * KCH; i += 256) {    // K rows [key][HD], chunk ^ (key & (KCH-1))
-            int key = i / KCH, ch = i - key * KCH;
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (k0 + key < T) u = *reinterpret_cast<const uint4*>(kbase + (long)(k0 + key) * HD + ch * 8);
-            *reinterpret_cast<uint4*>(&s_k[key * HD + ((ch ^ (key & (KCH - 1))) << 3)]) = u;
-        }
-        for (int i = tid; i < HD * (KT / 8); i += 256) {   // V^T rows [d][KT], chunk ^ (d & 7)
-            int d = i / (KT / 8), ch = i - d * (KT / 8);
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (k0 + ch * 8 < T) u = *reinterpret_cast<const uint4*>(vbase + (long)d * vt_stride + k0 + ch * 8);
-            *reinterpret_cast<uint4*>(&s_v[d * KT + ((ch ^ (d & 7)) << 3)]) = u;
-        }
+        __syncthreads();                               // previous tile's LDS reads are done
+        stage(k0);
         __syncthreads();
-        if (k0 <= qw + 31 && qw < T) {                 // this wave has unmasked keys in the tile
-            f32x4 sc[2][4];
+        if (k0 <= qw + QW - 1 && qw < T) {                 // this wave has unmasked keys in the tile
+            f32x4 sc[MT][4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 mfma_bf16x8 kf[KS];
@@ -273,7 +297,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
                 for (int s = 0; s < KS; ++s)
                     kf[s] = *reinterpret_cast<const mfma_bf16x8*>(&s_k[key * HD + (((s * 4 + fc) ^ (key & (KCH - 1))) << 3)]);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
+                for (int mi = 0; mi < MT; ++mi) {
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[mi][s], kf[s], acc, 0, 0, 0);
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
             }
             // online softmax; lane holds rows mi*16 + fc*4 + j, key column nt*16 + fr
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MT; ++mi) {
                 float alpha[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -322,47 +346,58 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ks = 0; ks < KT / 32; ++ks) {
-                mfma_bf16x8 pa[2];
+                mfma_bf16x8 pa[MT];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
                     pa[mi] = *reinterpret_cast<const mfma_bf16x8*>(&s_p[wave][mi * 16 + fr][ks * 32 + fc * 8]);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int dr = d * 16 + fr;
                     mfma_bf16x8 vf = *reinterpret_cast<const mfma_bf16x8*>(&s_v[dr * KT + (((ks * 4 + fc) ^ (dr & 7)) << 3)]);
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) o[mi][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[mi], vf, o[mi][d], 0, 0, 0);
+                    for (int mi = 0; mi < MT; ++mi) o[mi][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[mi], vf, o[mi][d], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
+    // ---- output: normalise, stage the wave's 32 x HD tile in LDS (K/V images are dead), 16-byte row stores ----
+    __syncthreads();
+    bf16_t* s_o = s_kv + wave * (QW * HD);                      // 4 waves x QW x HD bf16 <= 2*KT*HD elements
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = qw + mi * 16 + fc * 4 + j;
-            if (r < T) {
-                const float invl = 1.0f / l_run[mi][j];
-                bf16_t* dst = out + ((long)(row0 + r) * heads + h) * HD;
+            const float invl = 1.0f / l_run[mi][j];
+            const int r = mi * 16 + fc * 4 + j;
 #pragma unroll
-                for (int d = 0; d < DT; ++d) dst[d * 16 + fr] = f32_to_bf16(o[mi][d][j] * invl);
-            }
+            for (int d = 0; d < DT; ++d) s_o[r * HD + d * 16 + fr] = f32_to_bf16(o[mi][d][j] * invl);
         }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < QW * KCH; i += 64) {
+        const int r = i / KCH, ch = i - r * KCH;
+        if (qw + r < T)
+            *reinterpret_cast<uint4*>(out + ((long)(row0 + qw + r) * heads + h) * HD + ch * 8) =
+                *reinterpret_cast<const uint4*>(&s_o[r * HD + ch * 8]);
+    }
 }
 
 void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt, int vt_stride, const int* cu,
                               const int* slot_of_clip, int n_clips, int max_len, int heads, bf16_t* out,
                               hipStream_t s) {
     if (n_clips <= 0 || max_len <= 0) return;
-    dim3 grid(cdiv(max_len, 128), heads, n_clips);
+    static const int mt = getenv("QASR_PA_MT") ? atoi(getenv("QASR_PA_MT")) : 1;      // A/B knob: row tiles per wave
     const float scale = 1.0f / sqrtf((float)cache.hd);
-    if (cache.hd == 128)
-        hipLaunchKernelGGL(prefill_attention_kernel<128>, grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu,
-                           slot_of_clip, heads, out, scale);
+    if (cache.hd == 128 && mt == 2)
+        hipLaunchKernelGGL((prefill_attention_kernel<128, 2>), dim3(cdiv(max_len, 128), heads, n_clips), dim3(256), 0, s,
+                           qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
+    else if (cache.hd == 128)
+        hipLaunchKernelGGL((prefill_attention_kernel<128, 1>), dim3(cdiv(max_len, 64), heads, n_clips), dim3(256), 0, s,
+                           qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
     else if (cache.hd == 32)
-        hipLaunchKernelGGL(prefill_attention_kernel<32>, grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu,
-                           slot_of_clip, heads, out, scale);
+        hipLaunchKernelGGL((prefill_attention_kernel<32, 2>), dim3(cdiv(max_len, 128), heads, n_clips), dim3(256), 0, s,
+                           qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
     else
         throw std::invalid_argument("prefill attention: head_dim must be 32 or 128");
 }
@@ -1072,8 +1107,10 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
         if (act) {
             const bf16_t* nw = isq ? qn_w : kn_w;
             float o1, o2;
+            // rope_cos / rope_sin are per-batch-row rows for the CURRENT position (written by the previous
+            // greedy_finalize), so this load does not depend on the ctx_len load
             norm_rope_pair(x1, x2, bf16_to_f32(nw[lane]), bf16_to_f32(nw[lane + HALF]), inv,
-                           rope_cos[(long)pos * HALF + lane], rope_sin[(long)pos * HALF + lane], o1, o2);
+                           rope_cos[(long)b * HALF + lane], rope_sin[(long)b * HALF + lane], o1, o2);
             if (isq) {
                 s_q[wave][lane] = o1;
                 s_q[wave][lane + HALF] = o2;
@@ -1209,9 +1246,10 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
                        kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale)
     if (hd == 128 && rep == 2) {
         if (nw == 16 && unr == 2) QASR_DA_GO(128, 2, 16);
+        else if (nw == 16 && unr == 3) QASR_DA_GO(128, 3, 16);
         else if (nw == 16) QASR_DA_GO(128, 4, 16);
-        else if (unr == 1) QASR_DA_GO(128, 1, 8);
         else if (unr == 2) QASR_DA_GO(128, 2, 8);
+        else if (unr == 8) QASR_DA_GO(128, 8, 8);
         else QASR_DA_GO(128, 4, 8);
     } else if (hd == 32 && rep == 2) {
         QASR_DA_GO(32, 2, 8);
@@ -1225,10 +1263,18 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
 __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __restrict__ part_val,
                                                               const int* __restrict__ part_idx, int n_parts,
                                                               GreedyState st, int advance_ctx,
-                                                              const bf16_t* __restrict__ embed, bf16_t* __restrict__ x, int H) {
+                                                              const bf16_t* __restrict__ embed, bf16_t* __restrict__ x, int H,
+                                                              RopeRows rr) {
     __shared__ float s_v[256];
     __shared__ int s_i[256];
     const int b = blockIdx.x, tid = threadIdx.x;
+    // position of the NEXT decode step for this row; its rope row is copied next to the batch row so that
+    // the attention kernels of that step need not chain a table lookup behind the ctx_len load
+    const int next_pos = st.ctx_len[b] + (advance_ctx ? 1 : 0);
+    if (tid < rr.half) {
+        rr.cos_rows[(long)b * rr.half + tid] = rr.cos_table[(long)next_pos * rr.half + tid];
+        rr.sin_rows[(long)b * rr.half + tid] = rr.sin_table[(long)next_pos * rr.half + tid];
+    }
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     for (int i = tid; i < n_parts; i += 256) {
@@ -1266,10 +1312,10 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
 }
 
 void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
-                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, hipStream_t s) {
+                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, RopeRows rr, hipStream_t s) {
     if (B <= 0) return;
     hipLaunchKernelGGL(greedy_finalize_kernel, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, st, advance_ctx,
-                       embed, x, H);
+                       embed, x, H, rr);
 }
 
 }  // namespace qasr

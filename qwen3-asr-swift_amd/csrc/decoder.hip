@@ -38,6 +38,16 @@ __global__ void add_scalar_kernel(int* p, int n, int v) {
     if (i < n) p[i] += v;
 }
 
+// teacher-forced path (no greedy_finalize): copy the rope rows of the current positions
+__global__ void refresh_rope_rows_kernel(const int* __restrict__ ctx_len, RopeRows rr) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < rr.half) {
+        const int p = ctx_len[b];
+        rr.cos_rows[(long)b * rr.half + t] = rr.cos_table[(long)p * rr.half + t];
+        rr.sin_rows[(long)b * rr.half + t] = rr.sin_table[(long)p * rr.half + t];
+    }
+}
+
 // decode-step weights are streamed as MFMA A fragments: keep a fragment-major copy (1.19 GB extra for 0.6B)
 const bf16_t* Engine::packed_copy(const bf16_t* w, int N, int K) {
     if (N % 16 != 0 || K % 32 != 0) return nullptr;
@@ -123,6 +133,8 @@ void Engine::finalize_decoder() {
         kcache_.back()->alloc(cache_bytes);
         vcache_.back()->alloc(cache_bytes);
     }
+    d_rope_rows_.alloc((size_t)2 * B * (hd / 2) * sizeof(float));
+    QASR_HIP(hipMemsetAsync(d_rope_rows_.p, 0, d_rope_rows_.bytes, stream_));
     d_vt_.alloc((size_t)B * cfg_.kv_heads * hd * vt_stride_ * sizeof(bf16_t));
     QASR_HIP(hipMemsetAsync(d_vt_.p, 0, d_vt_.bytes, stream_));   // masked keys multiply stale bytes by P = 0
     d_px_.alloc((size_t)max_pos_ * H * 2);
@@ -275,6 +287,12 @@ void Engine::run_prefill(bool want_logits) {
     QASR_HIP(hipGetLastError());
 }
 
+RopeRows Engine::rope_rows(int r0) const {
+    const int half = cfg_.head_dim / 2;
+    return RopeRows{d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), d_rope_rows_.as<float>() + (size_t)r0 * half,
+                    d_rope_rows_.as<float>() + (size_t)(cfg_.max_batch + r0) * half, half};
+}
+
 GreedyState Engine::greedy_rows(int r0) const {
     GreedyState g = gstate_;
     g.tokens += (size_t)r0 * (cfg_.max_new_tokens + 1);
@@ -302,8 +320,9 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         DecGemvArgs a{};
         a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
         decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, h, s);
+        const RopeRows rr = rope_rows(r0);
         decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
-                                d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv, at, s);
+                                rr.cos_rows, rr.sin_rows, kv, at, s);
         a.W = L.wo; a.Wp = L.wo_p; a.X = at; a.N = H; a.K = nq; a.out = x;
         decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
         a.W = L.wgu; a.Wp = L.wgu_p; a.X = x; a.N = 2 * I; a.K = H; a.out = act;
@@ -315,7 +334,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     run_lm_head(want_logits, r0, nr, s);
     if (greedy)
         greedy_finalize_launch(d_part_val_.as<float>() + (size_t)r0 * n_parts_, d_part_idx_.as<int>() + (size_t)r0 * n_parts_,
-                               n_parts_, gs, nr, 1, decw_.embed, x, H, s);
+                               n_parts_, gs, nr, 1, decw_.embed, x, H, rope_rows(r0), s);
 }
 
 // A whole step = `split` row groups.  The small-batch decode kernels are latency-bound (a 4..12 MB weight
@@ -370,7 +389,7 @@ void Engine::issue_decode_step(int split) {
     // LM head streams 311 MB of tied-embedding weights: once per step for all rows, not once per row group
     run_lm_head(false, 0, B, stream_);
     greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, B, 1, decw_.embed,
-                           d_dx_.as<bf16_t>(), cfg_.hidden, stream_);
+                           d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), stream_);
 }
 
 // Greedy loop (Qwen3ASR.swift:344-389): token 0 comes from the prompt pass; every further token costs
@@ -435,7 +454,7 @@ void Engine::batch_run() {
     QASR_HIP(hipEventRecord(ev_[2], s));
     run_prefill(false);
     greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, batch_, 0, decw_.embed,
-                           d_dx_.as<bf16_t>(), cfg_.hidden, s);
+                           d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), s);
     QASR_HIP(hipEventRecord(ev_[3], s));
     decode_loop();
     QASR_HIP(hipEventRecord(ev_[4], s));
@@ -492,9 +511,9 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             a.W = L.wdown; a.Wp = L.wdown_p; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
             decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
         } else if (which == 1) {
+            const RopeRows rr = rope_rows(0);
             decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn,
-                                    L.kn, cfg_.rms_eps, d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), kv,
-                                    d_dattn_.as<bf16_t>(), s);
+                                    L.kn, cfg_.rms_eps, rr.cos_rows, rr.sin_rows, kv, d_dattn_.as<bf16_t>(), s);
         } else {
             lm_head_launch(decw_.embed, decw_.embed_p, d_dx_.as<bf16_t>(), decw_.norm, cfg_.rms_eps, batch_, cfg_.vocab, H, nullptr,
                            d_part_val_.as<float>(), d_part_idx_.as<int>(), d_dh_.as<bf16_t>(), s);
@@ -574,6 +593,7 @@ void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
         *idx.as<int>() = tokens[i];
         QASR_HIP(hipMemcpyAsync(didx.p, idx.p, sizeof(int), hipMemcpyHostToDevice, stream_));
         gather_rows_launch(decw_.embed, didx.as<int>(), d_dx_.as<bf16_t>(), 1, cfg_.hidden, stream_);
+        hipLaunchKernelGGL(refresh_rope_rows_kernel, dim3(1), dim3(64), 0, stream_, gstate_.ctx_len, rope_rows(0));
         run_decode_step(true, false, 0, 1, stream_, true);
         hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(64), 0, stream_, gstate_.ctx_len, 1, 1);
         QASR_HIP(hipMemcpyAsync(logits + (size_t)i * cfg_.vocab, d_logits_.p, (size_t)cfg_.vocab * sizeof(float),

@@ -129,6 +129,7 @@ private:
     void issue_decode_step(int split);
     int decode_group_rows() const;
     GreedyState greedy_rows(int r0) const;
+    RopeRows rope_rows(int r0) const;
     void run_lm_head(bool want_logits, int r0, int nr, hipStream_t s);
     void reset_greedy_state(int max_tokens, bool ignore_eos);
     void decode_loop();
@@ -185,7 +186,7 @@ private:
         std::vector<DecLayerW> layers;
     } decw_;
     int max_prompt_ = 0, max_ctx_ = 0, max_pos_ = 0, vt_stride_ = 0;
-    DevBuf d_rope_cos_, d_rope_sin_;
+    DevBuf d_rope_cos_, d_rope_sin_, d_rope_rows_;    // tables [max_ctx][hd/2]; per-row copies for the next step
     std::vector<std::unique_ptr<DevBuf>> kcache_, vcache_;     // per layer
     DevBuf d_vt_;
     DevBuf d_px_, d_ph_, d_pqkv_, d_pqr_, d_pattn_, d_pact_;   // prefill (packed prompt positions)
