@@ -11,6 +11,7 @@
 // per lane along rows.
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 namespace qasr {
 
@@ -30,6 +31,7 @@ struct ADense {
         if (r.p && k < K) return *reinterpret_cast<const uint4*>(r.p + k);
         return make_uint4(0, 0, 0, 0);
     }
+    __device__ __forceinline__ const bf16_t* addr(const Row& r, int k) const { return (r.p && k < K) ? r.p + k : nullptr; }
 };
 
 // rows addressed through an element-offset table (packed valid tokens -> conv3 output rows)
@@ -43,6 +45,7 @@ struct ARowTable {
         if (r.p && k < K) return *reinterpret_cast<const uint4*>(r.p + k);
         return make_uint4(0, 0, 0, 0);
     }
+    __device__ __forceinline__ const bf16_t* addr(const Row& r, int k) const { return (r.p && k < K) ? r.p + k : nullptr; }
 };
 
 // Implicit GEMM for a 3x3 / stride 2 / pad 1 convolution over NHWC bf16 input [img][H][W][C].
@@ -76,6 +79,13 @@ struct AConv3x3s2 {
         if (!((r.mask >> tap) & 1u)) return make_uint4(0, 0, 0, 0);
         int kh = tap / 3, kw = tap - kh * 3;
         return *reinterpret_cast<const uint4*>(r.base + ((long)kh * W + kw) * C + ci);
+    }
+    __device__ __forceinline__ const bf16_t* addr(const Row& r, int k) const {
+        if (k >= K) return nullptr;
+        int tap = k / C, ci = k - tap * C;
+        if (!((r.mask >> tap) & 1u)) return nullptr;
+        int kh = tap / 3, kw = tap - kh * 3;
+        return r.base + ((long)kh * W + kw) * C + ci;
     }
 };
 
@@ -208,11 +218,148 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(ALoad aload, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same tiling, operands staged with direct-to-LDS loads (global_load_lds_dwordx4): no VGPR round trip and no
+// ds_write_b128 (LDS stores run at ~79 B/clk/CU on gfx950 and were the busiest pipe of the register-staged
+// loop).  One wave instruction fills 1 KiB of LDS linearly = 8 tile rows; the XOR chunk swizzle moves to the
+// per-lane SOURCE address (lane l of an 8-row group reads chunk (l%8) ^ (l/8)), the fragment reads keep the
+// same swizzle.  Masked chunks (row tail, K tail, conv padding taps) read a 16-byte block of zeros.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <class ALoad, class Epi, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw,
+                                                                     int M, int N, int K, Epi epi,
+                                                                     const bf16_t* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) char smem[2][2][GEMM_BM * 128];   // [buf][A|B][row*128B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbx = (N + GEMM_BN - 1) / GEMM_BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / nbx) * GEMM_BM, n0 = (bid % nbx) * GEMM_BN;
+
+    // staging: wave w, instruction i covers tile rows (w*4 + i)*8 .. +7; lane -> (row + lane/8, LDS slot lane%8)
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;              // source chunk = slot ^ (row & 7), rows are 8-aligned per group
+    typename ALoad::Row arow[4];
+    const bf16_t* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;
+        arow[i] = aload.row_init(m0 + r);
+        const int n = n0 + r;
+        wrow[i] = n < N ? Wt + (long)n * ldw : nullptr;
+    }
+    auto stage = [&](int buf, int kt) {
+        const int k = kt * GEMM_BK + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* pa = aload.addr(arow[i], k);
+            const bf16_t* pb = (wrow[i] && k < K) ? wrow[i] + k : nullptr;
+            const int off = (wave * 4 + i) * 1024;      // wave-uniform LDS base of this instruction
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa ? pa : zeros), (lds_ptr_t)&smem[buf][0][off], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb ? pb : zeros), (lds_ptr_t)&smem[buf][1][off], 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA completion is tracked by vmcnt only
+    __syncthreads();
+    const int fr = lane & 15, fc = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);       // in flight during this tile's MFMAs
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            mfma_bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][0][gemm_lds_off(wm * 64 + i * 16 + fr, fc + 4 * s)]);
+                b[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][1][gemm_lds_off(wn * 64 + i * 16 + fr, fc + 4 * s)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt+1 has landed (this wave's part) ...
+        __syncthreads();                                // ... and every wave's part after the barrier
+    }
+
+    float* ct = reinterpret_cast<float*>(&smem[0][0][0]) + wave * (64 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    if (MODE == 0) {
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            int row = it * 4 + er;
+            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + ec;
+            if (m < M && n < N) {
+                float4 v = *reinterpret_cast<const float4*>(&ct[row * 64 + ec]);
+                epi(m, n, v);
+            }
+        }
+    } else {
+        const int er = lane >> 3, e4 = (lane & 7) * 4, blk = e4 >> 4, e = e4 & 15;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            int row = it * 8 + er;
+            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + blk * 32;
+            if (m < M && n < N) {
+                float4 g = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + e]);
+                float4 u = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + 16 + e]);
+                float4 v;
+                v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
+                v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
+                epi(m, n / 2 + e, v);
+            }
+        }
+    }
+}
+
+// 256 bytes of zeros in HBM for masked direct-to-LDS chunks (one per translation unit)
+inline const bf16_t* gemm_zero_block() {
+    static bf16_t* z = nullptr;
+    if (!z) {
+        QASR_HIP(hipMalloc(&z, 256));
+        QASR_HIP(hipMemset(z, 0, 256));
+    }
+    return z;
+}
+inline bool gemm_use_glds() {
+    static const int v = getenv("QASR_GEMM_GLDS") ? atoi(getenv("QASR_GEMM_GLDS")) : 1;
+    return v != 0;
+}
+
 template <class ALoad, class Epi>
 inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
+    if (gemm_use_glds())
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block());
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
 }
 
 template <class ALoad, class Epi>
@@ -220,7 +367,11 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
     if (M <= 0 || N <= 0) return;
     if (N % 32 != 0) throw std::invalid_argument("swiglu gemm: fused width must be a multiple of 32");
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
+    if (gemm_use_glds())
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block());
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
 }
 
 // ------------------------------------------------------------------------------------------------
