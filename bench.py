@@ -151,14 +151,14 @@ def main():
     if rank == 0:
         audio_s = world * B * args.seconds * args.steps
         ms_step = dt / args.steps * 1e3
-        # dominant kernel by GPU time (profiles/r01_v4_bench_kernel_stats.csv: 32 %): decode_attention_kernel
+        # dominant kernel by GPU time (profiles/r01_v5_bench_kernel_stats.csv: 32 %): decode_attention_kernel
         dom_ms, dom_bytes = probe["decode_attn"]
         traffic, traffic_note = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")
         if os.path.exists(pmc_path):       # measured in separate rocprofv3 --pmc passes (see the file's "source")
             pmc = json.load(open(pmc_path))
             traffic = pmc.get("decode_attention_bytes")
-            traffic_note = ("profiles/r01_v4_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc "
+            traffic_note = ("profiles/r01_v5_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc "
                             "passes at mean context 414 where the algorithmic bytes are 54.3e6 (ratio 1.015)")
         out = {
             "metric": "audio-seconds/sec (RTF^-1) Qwen3-ASR-0.6B, 30 s@16 kHz, b=32 per GPU",
