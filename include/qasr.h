@@ -81,6 +81,13 @@ typedef struct qasr_options {
     int32_t n_context;
     const int32_t* language_ids;       /* tokenised "language XX" hint (:228-232) or NULL */
     int32_t n_language;
+    /* Qwen3DecodingOptions (Qwen3ASR.swift:13-51).  All zero = greedy fast path (isGreedyFastPath, :300-304).
+     * Any non-default value selects the reference's slow path: logits come back to the host every step and
+     * pickNextToken (:449-520) runs on the CPU. */
+    float repetition_penalty;          /* 0 or 1.0 = off; HF sign-aware penalty on already generated ids */
+    int32_t no_repeat_ngram_size;      /* 0 = off */
+    float temperature;                 /* 0 = argmax; > 0 = Gumbel-max sampling */
+    uint64_t seed;                     /* sampler seed (the reference uses the system RNG) */
 } qasr_options;
 
 typedef struct qasr_result {
@@ -137,6 +144,16 @@ int qasr_transcribe_batch(qasr_engine* e, const float* const* pcm, const size_t*
  * returns bytes written (excluding NUL) or -1. */
 int qasr_detokenize(qasr_engine* e, const int32_t* tokens, int32_t n, char* buf, size_t cap);
 int qasr_stt_vtable(qasr_engine* e, sc_stt_vtable_t* out);
+/* BPE encode of a UTF-8 string with the engine's vocab + merges (Qwen3Tokenizer.encode, Tokenizer.swift:195-289):
+ * the reference encodes `context` and "language XX" with it (Qwen3ASR.swift:203-206,228-232).  Returns the
+ * number of ids written or -1.  qasr_set_merges installs merges.txt content for engines built in memory. */
+int qasr_encode_text(qasr_engine* e, const char* utf8, int32_t* ids, int32_t cap);
+int qasr_set_merges(qasr_engine* e, const char* merges_txt);
+/* pickNextToken (Qwen3ASR.swift:449-520) on a host logits vector; pure CPU function, no engine needed.
+ * rng_state: in/out sampler state (only used when temperature > 0), may be NULL. */
+int32_t qasr_pick_next_token(const float* logits, int32_t vocab, const int32_t* generated, int32_t n_generated,
+                             float repetition_penalty, int32_t no_repeat_ngram_size, float temperature,
+                             uint64_t* rng_state);
 
 /* ---- split batch API: H2D / compute / D2H separately timed -------------------------------- */
 int qasr_batch_begin(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B,

@@ -54,3 +54,69 @@ def strip_asr_prefix(raw):
     if i >= 0:
         return raw[i + len("<asr_text>"):].strip(_WHITESPACES)
     return raw
+
+
+# ---- encode (text -> ids): restatement of Tokenizer.swift:183-289 -------------------------------------------
+
+def _pre_tokenize(text):
+    """Tokenizer.swift:220-241: split before every space / newline / tab, the whitespace char starts the next
+    word; each word is mapped to its byte-level (GPT-2) representation."""
+    words, cur = [], ""
+    for ch in text:
+        if ch in (" ", "\n", "\t"):
+            if cur:
+                words.append(cur)
+            cur = ch
+        else:
+            cur += ch
+    if cur:
+        words.append(cur)
+    return ["".join(_B2U[b] for b in w.encode("utf-8")) for w in words]
+
+
+def _bpe(word, ranks):
+    """Tokenizer.swift:244-278: repeatedly merge the lowest-ranked adjacent pair (all its occurrences)."""
+    pieces = list(word)
+    while len(pieces) > 1:
+        best, best_rank = None, None
+        for i in range(len(pieces) - 1):
+            r = ranks.get(pieces[i] + " " + pieces[i + 1])
+            if r is not None and (best_rank is None or r < best_rank):
+                best_rank, best = r, (pieces[i], pieces[i + 1])
+        if best is None:
+            break
+        out, i = [], 0
+        while i < len(pieces):
+            if i < len(pieces) - 1 and pieces[i] == best[0] and pieces[i + 1] == best[1]:
+                out.append(best[0] + best[1])
+                i += 2
+            else:
+                out.append(pieces[i])
+                i += 1
+        pieces = out
+    return pieces
+
+
+def parse_merges(text):
+    """Tokenizer.swift:92-106: rank = line index; '#'-prefixed and empty lines are skipped."""
+    ranks = {}
+    for idx, line in enumerate(text.split("\n")):
+        if line.startswith("#") or not line:
+            continue
+        parts = line.split(" ")
+        if len(parts) != 2:
+            continue
+        ranks[parts[0] + " " + parts[1]] = idx
+    return ranks
+
+
+def encode(text, token_to_id, ranks):
+    """Tokenizer.swift:195-217 (+ character fallback :281-289 when no merges are loaded)."""
+    if not ranks:
+        return [token_to_id[c] for c in text if c in token_to_id]
+    ids = []
+    for w in _pre_tokenize(text):
+        for piece in _bpe(w, ranks):
+            if piece in token_to_id:
+                ids.append(token_to_id[piece])
+    return ids

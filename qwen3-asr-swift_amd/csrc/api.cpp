@@ -112,6 +112,21 @@ int qasr_set_vocab(qasr_engine* e, const int32_t* ids, const char* const* tokens
     QASR_GUARD(e, e->impl->set_vocab(ids, tokens, n));
 }
 
+int qasr_set_merges(qasr_engine* e, const char* merges_txt) {
+    if (!e || !merges_txt) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->set_merges(merges_txt));
+}
+
+int qasr_encode_text(qasr_engine* e, const char* utf8, int32_t* ids, int32_t cap) {
+    if (!e || !utf8 || !ids || cap < 0) return -1;
+    try {
+        std::vector<int32_t> v = e->impl->encode_text(utf8);
+        if ((int32_t)v.size() > cap) { fail(e, QASR_ERR_CAPACITY, "encode_text: buffer too small"); return -1; }
+        std::memcpy(ids, v.data(), v.size() * sizeof(int32_t));
+        return (int32_t)v.size();
+    } catch (const std::exception& ex) { fail(e, QASR_ERR_INVALID, ex.what()); return -1; }
+}
+
 int qasr_detokenize(qasr_engine* e, const int32_t* tokens, int32_t n, char* buf, size_t cap) {
     if (!e || !tokens || !buf || cap == 0 || n < 0) return -1;
     try {

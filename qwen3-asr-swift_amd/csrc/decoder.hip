@@ -430,12 +430,73 @@ void Engine::decode_loop() {
     }
 }
 
+int32_t pick_next_token(const float* logits, int32_t vocab, const int32_t* generated, int32_t n_gen,
+                        float repetition_penalty, int32_t ngram, float temperature, uint64_t* rng_state);
+
+__global__ void set_ints_kernel(int* dst, const int* src, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// Slow path (generateSlow, Qwen3ASR.swift:396-433): the logits of every row come back to the host each step and
+// pickNextToken runs on the CPU, exactly like the reference; the step itself is the same HIP decode step.
+void Engine::decode_loop_slow() {
+    const int B = batch_, V = cfg_.vocab, H = cfg_.hidden, stride = cfg_.max_new_tokens + 1;
+    std::vector<float> logits((size_t)B * V);
+    std::vector<std::vector<int32_t>> gen(B);
+    std::vector<int> done(B, 0), next(B, 0);
+    std::vector<uint64_t> rng(B);
+    for (int b = 0; b < B; ++b) rng[b] = opt_seed_ * 0x9e3779b97f4a7c15ull + (uint64_t)b + 1;
+    HostBuf h_tok;
+    h_tok.alloc((size_t)B * sizeof(int));
+    DevBuf d_tok;
+    d_tok.alloc((size_t)B * sizeof(int));
+    for (int step = 0; step < cur_max_tokens_; ++step) {
+        QASR_HIP(hipMemcpyAsync(logits.data(), d_logits_.p, logits.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        QASR_HIP(hipStreamSynchronize(stream_));
+        bool all_done = true;
+        for (int b = 0; b < B; ++b) {
+            if (done[b]) continue;
+            const int32_t t = pick_next_token(&logits[(size_t)b * V], V, gen[b].data(), (int32_t)gen[b].size(),
+                                              opt_rep_penalty_, opt_ngram_, opt_temperature_, &rng[b]);
+            gen[b].push_back(t);
+            next[b] = t;
+            if ((t == cfg_.tok_im_end && !cur_ignore_eos_) || (int)gen[b].size() >= cur_max_tokens_) done[b] = 1;
+            all_done = all_done && done[b];
+        }
+        if (all_done || step + 1 >= cur_max_tokens_) break;
+        // feed the picked ids: x = embed[token], rope rows for the current positions, one decode step with logits
+        std::memcpy(h_tok.p, next.data(), (size_t)B * sizeof(int));
+        QASR_HIP(hipMemcpyAsync(d_tok.p, h_tok.p, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream_));
+        gather_rows_launch(decw_.embed, d_tok.as<int>(), d_dx_.as<bf16_t>(), B, H, stream_);
+        hipLaunchKernelGGL(refresh_rope_rows_kernel, dim3(B), dim3(64), 0, stream_, gstate_.ctx_len, rope_rows(0));
+        run_decode_step(true, false, 0, B, stream_, true);
+        hipLaunchKernelGGL(add_scalar_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream_, gstate_.ctx_len, B, 1);
+        ++steps_done_;
+    }
+    // publish through the same device-side result block the fast path uses
+    std::vector<int> flat((size_t)B * stride, -1), lens(B);
+    for (int b = 0; b < B; ++b) {
+        std::copy(gen[b].begin(), gen[b].end(), flat.begin() + (size_t)b * stride);
+        lens[b] = (int)gen[b].size();
+    }
+    QASR_HIP(hipMemcpyAsync(gstate_.tokens, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    QASR_HIP(hipMemcpyAsync(gstate_.lens, lens.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream_));
+    QASR_HIP(hipStreamSynchronize(stream_));
+}
+
 // ---- batch pipeline --------------------------------------------------------------------------------
 void Engine::batch_begin(const float* const* pcm, const size_t* n, size_t B, const qasr_options* opt) {
     if (!finalized_) throw std::runtime_error("weights not finalized");
     if (B == 0) throw std::invalid_argument("empty batch");
     int max_tokens = opt && opt->max_tokens > 0 ? opt->max_tokens : cfg_.max_new_tokens;
     if (max_tokens > cfg_.max_new_tokens) throw std::length_error("max_tokens exceeds engine capacity");
+    // Qwen3DecodingOptions: anything but the defaults selects the slow path (isGreedyFastPath, Qwen3ASR.swift:300-304)
+    opt_rep_penalty_ = opt && opt->repetition_penalty != 0.0f ? opt->repetition_penalty : 1.0f;
+    opt_ngram_ = opt ? opt->no_repeat_ngram_size : 0;
+    opt_temperature_ = opt ? opt->temperature : 0.0f;
+    opt_seed_ = opt ? opt->seed : 0;
+    slow_path_ = !(opt_rep_penalty_ == 1.0f && opt_ngram_ == 0 && opt_temperature_ == 0.0f);
     upload_pcm(pcm, n, B);
     plan_encoder();
     std::vector<int> n_audio;
@@ -452,11 +513,13 @@ void Engine::batch_run() {
     QASR_HIP(hipEventRecord(ev_[1], s));
     run_encoder();
     QASR_HIP(hipEventRecord(ev_[2], s));
-    run_prefill(false);
-    greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, batch_, 0, decw_.embed,
-                           d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), s);
+    run_prefill(slow_path_);
+    if (!slow_path_)
+        greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, batch_, 0, decw_.embed,
+                               d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), s);
     QASR_HIP(hipEventRecord(ev_[3], s));
-    decode_loop();
+    if (slow_path_) decode_loop_slow();
+    else decode_loop();
     QASR_HIP(hipEventRecord(ev_[4], s));
 }
 

@@ -105,6 +105,8 @@ public:
 
     // tokenizer (R9)
     void set_vocab(const int32_t* ids, const char* const* tokens, size_t n);
+    void set_merges(const std::string& merges_txt);
+    std::vector<int32_t> encode_text(const std::string& text) const;
     void load_vocab_files(const std::string& dir);
     std::string detokenize(const int32_t* tokens, int n, bool strip_asr_prefix) const;
     std::string result_text;              // owned result storage for qasr_transcribe / vtable
@@ -215,6 +217,15 @@ private:
 
     // ---- tokenizer -----------------------------------------------------------------------------
     std::unordered_map<int32_t, std::string> id_to_token_;
+    std::unordered_map<std::string, int32_t> token_to_id_;
+    std::unordered_map<std::string, int> merge_rank_;
+
+    // ---- slow decoding path (Qwen3DecodingOptions) ---------------------------------------------
+    bool slow_path_ = false;
+    float opt_rep_penalty_ = 1.0f, opt_temperature_ = 0.0f;
+    int opt_ngram_ = 0;
+    uint64_t opt_seed_ = 0;
+    void decode_loop_slow();
 };
 
 }  // namespace qasr

@@ -94,7 +94,108 @@ static std::string trim_ws(const std::string& s) {
 }
 
 void Engine::set_vocab(const int32_t* ids, const char* const* tokens, size_t n) {
-    for (size_t i = 0; i < n; ++i) id_to_token_[ids[i]] = tokens[i];
+    for (size_t i = 0; i < n; ++i) {
+        id_to_token_[ids[i]] = tokens[i];
+        token_to_id_[tokens[i]] = ids[i];
+    }
+}
+
+// merges.txt (Tokenizer.swift:92-106): rank = line index, '#' lines and empty lines skipped
+void Engine::set_merges(const std::string& text) {
+    merge_rank_.clear();
+    size_t pos = 0;
+    int idx = 0;
+    while (pos <= text.size()) {
+        size_t nl = text.find('\n', pos);
+        if (nl == std::string::npos) nl = text.size();
+        std::string line = text.substr(pos, nl - pos);
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] != '#') {
+            size_t sp = line.find(' ');
+            if (sp != std::string::npos && line.find(' ', sp + 1) == std::string::npos) merge_rank_[line] = idx;
+        }
+        ++idx;
+        pos = nl + 1;
+    }
+}
+
+static void put_cp(std::string& s, unsigned cp) {
+    if (cp < 0x80) s += (char)cp;
+    else if (cp < 0x800) { s += (char)(0xC0 | (cp >> 6)); s += (char)(0x80 | (cp & 0x3F)); }
+    else { s += (char)(0xE0 | (cp >> 12)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+}
+
+// GPT-2 byte -> unicode (Tokenizer.swift:146-172)
+static unsigned byte_to_unicode(unsigned char b) {
+    static unsigned table[256];
+    static bool init = false;
+    if (!init) {
+        bool direct[256] = {};
+        for (int x = 33; x <= 126; ++x) direct[x] = true;
+        for (int x = 0xA1; x <= 0xAC; ++x) direct[x] = true;
+        for (int x = 0xAE; x <= 0xFF; ++x) direct[x] = true;
+        int n = 0;
+        for (int x = 0; x < 256; ++x) table[x] = direct[x] ? (unsigned)x : 0x100u + n++;
+        init = true;
+    }
+    return table[b];
+}
+
+// Qwen3Tokenizer.encode (Tokenizer.swift:195-289): whitespace pre-tokenisation (the space / newline / tab
+// starts the next word), byte-level mapping, lowest-rank-pair BPE; ids of pieces missing from the vocab are
+// dropped; without merges: per-character lookup.
+std::vector<int32_t> Engine::encode_text(const std::string& text) const {
+    std::vector<int32_t> ids;
+    if (merge_rank_.empty()) {
+        for (size_t i = 0; i < text.size();) {
+            size_t len;
+            next_cp(text, i, len);
+            auto it = token_to_id_.find(text.substr(i, len));
+            if (it != token_to_id_.end()) ids.push_back(it->second);
+            i += len;
+        }
+        return ids;
+    }
+    std::vector<std::string> words;
+    std::string cur;
+    for (char ch : text) {
+        if (ch == ' ' || ch == '\n' || ch == '\t') {
+            if (!cur.empty()) words.push_back(cur);
+            cur.assign(1, ch);
+        } else {
+            cur += ch;
+        }
+    }
+    if (!cur.empty()) words.push_back(cur);
+    for (const std::string& w : words) {
+        std::vector<std::string> pieces;
+        for (unsigned char b : w) {
+            std::string p;
+            put_cp(p, byte_to_unicode(b));
+            pieces.push_back(p);
+        }
+        while (pieces.size() > 1) {
+            int best_rank = -1;
+            size_t best_i = 0;
+            for (size_t i = 0; i + 1 < pieces.size(); ++i) {
+                auto it = merge_rank_.find(pieces[i] + " " + pieces[i + 1]);
+                if (it != merge_rank_.end() && (best_rank < 0 || it->second < best_rank)) { best_rank = it->second; best_i = i; }
+            }
+            if (best_rank < 0) break;
+            const std::string a = pieces[best_i], b = pieces[best_i + 1];
+            std::vector<std::string> out;
+            for (size_t i = 0; i < pieces.size();) {
+                if (i + 1 < pieces.size() && pieces[i] == a && pieces[i + 1] == b) { out.push_back(a + b); i += 2; }
+                else { out.push_back(pieces[i]); i += 1; }
+            }
+            pieces.swap(out);
+        }
+        for (const std::string& p : pieces) {
+            auto it = token_to_id_.find(p);
+            if (it != token_to_id_.end()) ids.push_back(it->second);
+        }
+    }
+    return ids;
 }
 
 static bool read_file(const std::string& path, std::string& out) {
@@ -112,16 +213,20 @@ void Engine::load_vocab_files(const std::string& dir) {
     Json v = JsonParser(txt.data(), txt.size()).parse();
     if (v.type != Json::Obj) throw std::runtime_error("vocab.json: expected {token: id}");
     for (auto& kv : v.obj)
-        if (kv.second.type == Json::Num) id_to_token_[(int32_t)kv.second.num] = kv.first;
+        if (kv.second.type == Json::Num) { id_to_token_[(int32_t)kv.second.num] = kv.first; token_to_id_[kv.first] = (int32_t)kv.second.num; }
     if (read_file(dir + "/tokenizer_config.json", txt)) {
         Json c = JsonParser(txt.data(), txt.size()).parse();
         const Json* added = c.get("added_tokens_decoder");
         if (added && added->type == Json::Obj)
             for (auto& kv : added->obj) {
                 const Json* content = kv.second.get("content");
-                if (content && content->type == Json::Str) id_to_token_[(int32_t)std::stol(kv.first)] = content->str;
+                if (content && content->type == Json::Str) {
+                    id_to_token_[(int32_t)std::stol(kv.first)] = content->str;
+                    token_to_id_[content->str] = (int32_t)std::stol(kv.first);
+                }
             }
     }
+    if (read_file(dir + "/merges.txt", txt)) set_merges(txt);
 }
 
 std::string Engine::detokenize(const int32_t* tokens, int n, bool strip_asr_prefix) const {

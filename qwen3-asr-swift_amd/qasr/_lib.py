@@ -23,7 +23,9 @@ class QasrConfig(C.Structure):
 class QasrOptions(C.Structure):
     _fields_ = [("max_tokens", C.c_int32), ("ignore_eos", C.c_int32),
                 ("context_ids", C.POINTER(C.c_int32)), ("n_context", C.c_int32),
-                ("language_ids", C.POINTER(C.c_int32)), ("n_language", C.c_int32)]
+                ("language_ids", C.POINTER(C.c_int32)), ("n_language", C.c_int32),
+                ("repetition_penalty", C.c_float), ("no_repeat_ngram_size", C.c_int32),
+                ("temperature", C.c_float), ("seed", C.c_uint64)]
 
 
 class QasrResult(C.Structure):
@@ -67,6 +69,9 @@ SIGNATURES = {
     "qasr_transcribe_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(QasrOptions), _I, _I]),
     "qasr_detokenize": (C.c_int, [_E, _I, C.c_int32, C.c_char_p, C.c_size_t]),
     "qasr_stt_vtable": (C.c_int, [_E, _P(ScSttVtable)]),
+    "qasr_encode_text": (C.c_int, [_E, C.c_char_p, _I, C.c_int32]),
+    "qasr_set_merges": (C.c_int, [_E, C.c_char_p]),
+    "qasr_pick_next_token": (C.c_int32, [_F, C.c_int32, _I, C.c_int32, C.c_float, C.c_int32, C.c_float, _P(C.c_uint64)]),
     "qasr_batch_begin": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, _P(QasrOptions)]),
     "qasr_batch_run": (C.c_int, [_E]),
     "qasr_batch_rewind": (C.c_int, [_E]),

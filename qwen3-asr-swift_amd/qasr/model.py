@@ -92,9 +92,12 @@ class Qwen3ASRModel:
         toks = (C.c_char_p * len(ids))(*[t.encode("utf-8") for t in id_to_token.values()])
         self._check(self.lib.qasr_set_vocab(self.h, _iptr(ids), toks, len(ids)))
 
-    def _options(self, max_tokens=0, ignore_eos=False, context_ids=None, language_ids=None):
+    def _options(self, max_tokens=0, ignore_eos=False, context_ids=None, language_ids=None,
+                 repetition_penalty=1.0, no_repeat_ngram_size=0, temperature=0.0, seed=0):
         o = _lib.QasrOptions()
         o.max_tokens, o.ignore_eos = int(max_tokens), int(bool(ignore_eos))
+        o.repetition_penalty, o.no_repeat_ngram_size = float(repetition_penalty), int(no_repeat_ngram_size)
+        o.temperature, o.seed = float(temperature), int(seed)
         self._keep = []
         for name, ids in (("context", context_ids), ("language", language_ids)):
             if ids:
@@ -105,15 +108,30 @@ class Qwen3ASRModel:
         return o
 
     # ---- transcribe -------------------------------------------------------------------------------
+    def encode_text(self, text):
+        """Qwen3Tokenizer.encode (Tokenizer.swift:195-289) with the engine's vocab + merges."""
+        raw = text.encode("utf-8")
+        ids = np.zeros(4 * len(raw) + 8, dtype=np.int32)
+        n = self.lib.qasr_encode_text(self.h, raw, _iptr(ids), ids.shape[0])
+        if n < 0:
+            raise QasrError(self.lib.qasr_last_error(self.h).decode())
+        return ids[:n].tolist()
+
+    def set_merges(self, merges_txt):
+        self._check(self.lib.qasr_set_merges(self.h, merges_txt.encode("utf-8")))
+
     def transcribe(self, audio, sample_rate=16000, language=None, max_tokens=448, context=None,
-                   language_ids=None, context_ids=None):
-        """-> str.  `language` / `context` strings need a BPE *encoder*, which is outside the hot path
-        (the reference encodes them on the host, Qwen3ASR.swift:203-206,228-232): pass token ids."""
-        if language is not None or context is not None:
-            return "[qasr error: pass language_ids/context_ids (host-side BPE encode is out of scope)]"
+                   language_ids=None, context_ids=None, **decoding):
+        """-> str.  `language` / `context` strings are BPE-encoded like the reference does
+        (Qwen3ASR.swift:203-206: context; :228-232: "language " + lang); `decoding` = Qwen3DecodingOptions
+        fields (repetition_penalty, no_repeat_ngram_size, temperature, seed)."""
+        if context:
+            context_ids = self.encode_text(context)
+        if language is not None:
+            language_ids = self.encode_text("language " + language)
         pcm = np.ascontiguousarray(audio, dtype=np.float32)
         res = _lib.QasrResult()
-        o = self._options(max_tokens, False, context_ids, language_ids)
+        o = self._options(max_tokens, False, context_ids, language_ids, **decoding)
         rc = self.lib.qasr_transcribe(self.h, _fptr(pcm), pcm.shape[0], int(sample_rate), C.byref(o), C.byref(res))
         if rc != 0:
             return f"[qasr error: {self.lib.qasr_last_error(self.h).decode()}]"

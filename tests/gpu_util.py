@@ -55,9 +55,12 @@ class Engine:
         self.check(self.lib.qasr_encode(self.h, fptr(mel), mel.shape[1], fptr(out)))
         return out
 
-    def options(self, max_tokens=0, ignore_eos=False, context_ids=None, language_ids=None):
+    def options(self, max_tokens=0, ignore_eos=False, context_ids=None, language_ids=None,
+                repetition_penalty=1.0, no_repeat_ngram_size=0, temperature=0.0, seed=0):
         o = _lib.QasrOptions()
         o.max_tokens, o.ignore_eos = max_tokens, int(ignore_eos)
+        o.repetition_penalty, o.no_repeat_ngram_size = float(repetition_penalty), int(no_repeat_ngram_size)
+        o.temperature, o.seed = float(temperature), int(seed)
         self._keep = []
         for name, ids in (("context", context_ids), ("language", language_ids)):
             if ids:

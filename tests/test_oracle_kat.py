@@ -97,3 +97,24 @@ def test_window_lengths():
     assert encoder.window_lengths(2000, a) == [104, 104, 52]       # cu_seqlens [0,104,208,260]
     assert encoder.window_lengths(500, a) == [65]
     assert encoder.window_lengths(50, a) == [7]                    # single short chunk: no pad
+
+
+def test_bpe_encode_restatement():
+    """Qwen3Tokenizer.encode (Tokenizer.swift:195-289): whitespace starts the next word, byte-level mapping,
+    lowest-rank pair merged everywhere, ids of unknown pieces dropped; no merges -> per-character lookup."""
+    b2u = tokenizer.byte_to_unicode()
+    G, TAB = b2u[0x20], b2u[0x09]                      # 'Ġ' and 'ĉ'
+    vocab = {}
+    for b in range(256):
+        vocab.setdefault(b2u[b], len(vocab))
+    lines = ["#version: 0.2", "l a", "la n", G + " lan", "g u", "gu a", G + "lan gua"]
+    merges = "\n".join(lines) + "\n"
+    for line in lines[1:]:
+        a, b = line.split(" ")
+        vocab.setdefault(a + b, len(vocab))
+    ranks = tokenizer.parse_merges(merges)
+    assert ranks == {"l a": 1, "la n": 2, G + " lan": 3, "g u": 4, "gu a": 5, G + "lan gua": 6}
+    inv = {v: k for k, v in vocab.items()}
+    assert [inv[i] for i in tokenizer.encode("a language", vocab, ranks)] == ["a", G + "langua", "g", "e"]
+    assert "".join(inv[i] for i in tokenizer.encode("x\ty  z", vocab, ranks)) == "x" + TAB + "y" + G + G + "z"
+    assert tokenizer.encode("ab", {"a": 1, "b": 2}, {}) == [1, 2]
