@@ -127,3 +127,39 @@ def test_30s_clips_batch8_properties():
         assert eng.encode(mel).shape == (390, 1024)
     finally:
         eng.close()
+
+
+def test_1p7b_preset_geometry():
+    """Qwen3-ASR-1.7B preset (encoder 1024/24/16 -> 2048, decoder hidden 2048 / inter 6144; AudioEncoder.swift:51-68,
+    Configuration.swift:89-100) with 4 decoder/encoder layers to keep the CPU oracle affordable: exercises the
+    K = 2048 tuned GEMVs, the K = 6144 generic fallback and the 2048-wide persistent LM head."""
+    import dataclasses
+    a = dataclasses.replace(C.AUDIO_LARGE, layers=4)
+    t = dataclasses.replace(C.TEXT_LARGE, layers=4)
+    sd = synth.synth_state_dict(a, t, seed=2, init="stress")
+    eng = gpu_util.Engine("1.7B", max_batch=4, max_audio_seconds=4, max_new_tokens=16, enc_layers=4, dec_layers=4)
+    try:
+        assert (eng.cfg.hidden, eng.cfg.inter, eng.cfg.enc_d_model, eng.cfg.enc_out_dim, eng.cfg.bits) == (2048, 6144, 1024, 2048, 8)
+        eng.load_state_dict(sd)
+        model = pipeline.OracleModel(sd, a, t, C.TOKENS, P.DEVICE)
+        pcm = synth.synth_waveform(1, 2.0)
+        toks = eng.transcribe_batch([pcm], max_tokens=5, ignore_eos=True)[0]
+        with torch.no_grad():
+            mel = model.mel(pcm)
+            emb = model.encode(mel)
+            got_emb = eng.encode(mel)
+            assert got_emb.shape == (26, 2048)
+            assert np.linalg.norm(got_emb - P.bf16_round(emb).numpy()) / np.linalg.norm(emb.numpy()) < 1e-2
+            logits, state, _ = decoder.prefill(torch.from_numpy(got_emb), model.W, t, P.DEVICE, model.tok)
+            got = eng.prefill_logits(got_emb)
+            ref = logits.numpy()
+            assert np.abs(got - ref).max() <= _tol(ref) and np.linalg.norm(got - ref) / np.linalg.norm(ref) < 3e-2
+            for i, tk in enumerate(toks):
+                assert logits[tk] >= logits.max() - _tol(logits.numpy()), (i, tk)
+                if i + 1 < len(toks):
+                    logits = decoder.decode_step(tk, model.W, t, state, P.DEVICE)
+        four = [synth.synth_waveform(k, 1.0 + 0.5 * k) for k in range(4)]
+        b4 = eng.transcribe_batch(four, max_tokens=5, ignore_eos=True)
+        assert b4[1] == eng.transcribe_batch([four[1]], max_tokens=5, ignore_eos=True)[0]
+    finally:
+        eng.close()
