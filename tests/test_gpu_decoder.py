@@ -132,3 +132,23 @@ def test_no_graph_equals_graph(tiny):
     a = eng.transcribe_batch(clips, max_tokens=9, ignore_eos=True)
     b = eng.transcribe_batch(clips, max_tokens=9, ignore_eos=True)
     assert a == b
+
+
+def test_long_audio_multi_window(tiny):
+    """75 s of audio (7500 frames, 75 chunks, 975 tokens, 38 attention windows, prompt 991) through the whole
+    path on the tiny geometry: teacher-forced against the oracle, and the long clip does not disturb a short
+    one batched with it."""
+    sd = tiny[1]
+    e = gpu_util.Engine("tiny", max_audio_seconds=80, max_new_tokens=16, max_batch=2)
+    try:
+        e.load_state_dict(sd)
+        model = pipeline.OracleModel(sd, A, T, TOK, P.DEVICE)
+        long_clip, short = synth.synth_waveform(6, 75.0), synth.synth_waveform(7, 1.3)
+        out = e.transcribe_batch([long_clip, short], max_tokens=6, ignore_eos=True)
+        _teacher_forced_check(model, long_clip, out[0], 6, True)
+        assert e.transcribe_batch([short], max_tokens=6, ignore_eos=True)[0] == out[1]
+        mel = e.mel(long_clip)
+        assert mel.shape == (128, 7500)
+        assert e.encode(mel).shape == (975, T.hidden)
+    finally:
+        e.close()
