@@ -170,7 +170,7 @@ int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps);
 /* Dominant-kernel probe used by bench.py's roofline object: average duration (ms) of kernel
  * `which` over the last run measured with HIP events on the engine stream, plus its launch count
  * and algorithmic bytes per launch.  which: 0 = decode-step weight-streaming GEMV group,
- * 1 = decode attention, 2 = LM head. */
+ * 1 = decode attention, 2 = LM head; 3 / 4 = prompt-pass QKV / gate-up GEMM (bytes_per_launch then holds FLOPs). */
 int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch);
 
 /* ---- stage entry points (oracle diffing) -------------------------------------------------- */

@@ -577,6 +577,12 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             const RopeRows rr = rope_rows(0);
             decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn,
                                     L.kn, cfg_.rms_eps, rr.cos_rows, rr.sin_rows, kv, d_dattn_.as<bf16_t>(), s);
+        } else if (which == 3) {      // prompt-pass QKV GEMM shape (M = packed prompt rows, N = 4096, K = 1024)
+            gemm_nt(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, L.wqkv, H, n_pos_, nh * hd, H,
+                    EpiBiasActBf16<0>{d_pqkv_.as<bf16_t>(), (long)nh * hd, nullptr}, s);
+        } else if (which == 4) {      // prompt-pass gate/up GEMM with the SwiGLU epilogue
+            gemm_nt_swiglu(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, L.wgu, H, n_pos_, 2 * I, H,
+                           EpiBiasActBf16<0>{d_pact_.as<bf16_t>(), I, nullptr}, s);
         } else {
             lm_head_launch(decw_.embed, decw_.embed_p, d_dx_.as<bf16_t>(), decw_.norm, cfg_.rms_eps, batch_, cfg_.vocab, H, nullptr,
                            d_part_val_.as<float>(), d_part_idx_.as<int>(), d_dh_.as<bf16_t>(), s);
@@ -619,6 +625,8 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     double bytes = 0;
     if (which == 0) bytes = 2.0 * ((double)nh * hd * H + (double)H * nq + 2.0 * I * H + (double)H * I);
     else if (which == 1) { for (int b = 0; b < rows; ++b) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)ctx[b]; }
+    else if (which == 3) bytes = 2.0 * (double)n_pos_ * nh * hd * H;          // FLOPs for the GEMM probes
+    else if (which == 4) bytes = 2.0 * (double)n_pos_ * 2 * I * H;
     else bytes = 2.0 * (double)cfg_.vocab * H;
     *bytes_per_launch = bytes;
 }
