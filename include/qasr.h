@@ -134,6 +134,13 @@ void qasr_destroy(qasr_engine* e);
 const char* qasr_last_error(const qasr_engine* e);      /* e may be NULL: last create() failure */
 int qasr_input_sample_rate(const qasr_engine* e);       /* 16000 */
 
+/* ---- harness input ---------------------------------------------------------------------------- */
+/* PCM16 WAV reader (AudioFileLoader.loadWAV, Sources/AudioCommon/AudioFileLoader.swift:70-157, with the bounds
+ * checks pinned by Tests/Qwen3ASRTests/SecurityHardeningTests.swift:83-196): first channel, int16 / 32768.
+ * *samples is malloc'ed, release with qasr_free.  Pure CPU; malformed files return QASR_ERR_IO. */
+int qasr_load_wav(const char* path, float** samples, size_t* n_samples, int* sample_rate);
+void qasr_free(void* p);
+
 /* ---- transcribe --------------------------------------------------------------------------- */
 int qasr_transcribe(qasr_engine* e, const float* pcm, size_t n, int sample_rate,
                     const qasr_options* opt, qasr_result* out);

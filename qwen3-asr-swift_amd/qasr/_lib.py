@@ -65,6 +65,8 @@ SIGNATURES = {
     "qasr_destroy": (None, [_E]),
     "qasr_last_error": (C.c_char_p, [_E]),
     "qasr_input_sample_rate": (C.c_int, [_E]),
+    "qasr_load_wav": (C.c_int, [C.c_char_p, _P(_F), _P(C.c_size_t), _P(C.c_int)]),
+    "qasr_free": (None, [C.c_void_p]),
     "qasr_transcribe": (C.c_int, [_E, _F, C.c_size_t, C.c_int, _P(QasrOptions), _P(QasrResult)]),
     "qasr_transcribe_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(QasrOptions), _I, _I]),
     "qasr_detokenize": (C.c_int, [_E, _I, C.c_int32, C.c_char_p, C.c_size_t]),

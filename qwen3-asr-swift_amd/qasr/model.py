@@ -28,6 +28,19 @@ class QasrError(RuntimeError):
     pass
 
 
+def load_wav(path):
+    """AudioFileLoader.loadWAV (AudioFileLoader.swift:70-157) through the C ABI -> (float32 samples, rate)."""
+    lib = _lib.load(strict=True)
+    ptr, n, rate = C.POINTER(C.c_float)(), C.c_size_t(), C.c_int()
+    rc = lib.qasr_load_wav(str(path).encode(), C.byref(ptr), C.byref(n), C.byref(rate))
+    if rc != 0:
+        raise QasrError(f"invalid WAV file ({rc}): {path}")
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32), rate.value
+    finally:
+        lib.qasr_free(ptr)
+
+
 class Qwen3ASRModel:
     input_sample_rate = 16000
 

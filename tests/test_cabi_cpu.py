@@ -136,3 +136,60 @@ def test_sampler_temperature_statistics():
         hits += t == 9
     assert hits > 25
     assert _pick(peak, [], temperature=0.7, rng=5) == _pick(peak, [], temperature=0.7, rng=5)   # seeded => reproducible
+
+
+# ---- WAV reader hardening (data of Tests/Qwen3ASRTests/SecurityHardeningTests.swift:83-196) -----------------
+import struct  # noqa: E402
+
+
+def _build_wav(fmt=1, channels=1, rate=16000, bits=16, samples=(0, 1000, -1000, 2000, -2000, 3000, -3000, 0),
+               data_size=None, extra=b"", corrupt=False):
+    block = channels * (bits // 8)
+    fmt_chunk = struct.pack("<HHIIHH", fmt, channels, rate, rate * block, block, bits)
+    body = b"" if corrupt else b"".join(struct.pack("<h", s) for s in samples)
+    data = b"data" + struct.pack("<I", len(samples) * 2 if data_size is None else data_size) + body
+    total = 4 + 8 + len(fmt_chunk) + len(extra) + len(data)
+    return b"RIFF" + struct.pack("<I", total) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt_chunk)) + fmt_chunk + extra + data
+
+
+def _load(tmp_path, blob):
+    from qasr.model import load_wav
+    p = tmp_path / "t.wav"
+    p.write_bytes(blob)
+    return load_wav(p)
+
+
+def test_wav_valid_mono_and_stereo(tmp_path):
+    s, r = _load(tmp_path, _build_wav())
+    assert r == 16000 and len(s) == 8 and s[1] == np.float32(1000) / np.float32(32768)
+    s, r = _load(tmp_path, _build_wav(channels=2, samples=(100, -100, 200, -200, 300, -300, 400, -400)))
+    assert len(s) == 4 and np.allclose(s[:2], [100 / 32768.0, 200 / 32768.0])          # first channel only
+    s, _ = _load(tmp_path, _build_wav(data_size=4))                                      # claims 2 samples
+    assert len(s) == 2
+
+
+@pytest.mark.parametrize("blob", [
+    b"\x00" * 20,                                                  # too small
+    b"NOPE" + _build_wav()[4:],                                    # missing RIFF
+    _build_wav()[:8] + b"NOPE" + _build_wav()[12:],                # missing WAVE
+    _build_wav(channels=0),                                        # zero channels
+    _build_wav(data_size=99999),                                   # data chunk larger than the file
+    _build_wav().replace(b"data", b"xxxx"),                        # no data chunk
+    _build_wav(extra=b"LIST" + struct.pack("<I", 0xFFFFFFFF) + b"\x00" * 4),   # chunk with a huge size field
+    _build_wav(fmt=3), _build_wav(bits=8),                         # not PCM / not 16-bit
+], ids=["small", "riff", "wave", "zero_ch", "oversized", "nodata", "huge_chunk", "float", "8bit"])
+def test_wav_malformed_rejected(tmp_path, blob):
+    from qasr.model import QasrError
+    with pytest.raises(QasrError):
+        _load(tmp_path, blob)
+
+
+def test_wav_reference_fixture():
+    """The reference's own test clip (data fixture, Tests/Qwen3ASRTests/Resources/test_audio.wav): PCM16 mono
+    24 kHz, 20.0 s, speech in 5.19-8.34 s."""
+    from qasr.model import load_wav
+    s, r = load_wav(os.path.join(GOLDEN, "test_audio.wav"))
+    assert r == 24000 and len(s) == 480000
+    assert abs(float(np.abs(s).max()) - 0.715) < 0.01
+    active = np.nonzero(np.abs(s) > 0.02)[0]
+    assert 5.0 < active[0] / r < 5.4 and 8.2 < active[-1] / r < 8.5

@@ -163,3 +163,34 @@ def test_1p7b_preset_geometry():
         assert b4[1] == eng.transcribe_batch([four[1]], max_tokens=5, ignore_eos=True)[0]
     finally:
         eng.close()
+
+
+def test_real_speech_fixture(full):
+    """The reference's own test clip (20 s, digital silence around 3 s of speech) at full geometry.  The harness
+    resamples 24 kHz -> 16 kHz with scipy (the reference's AVAudioConverter is closed source and out of scope;
+    both sides get the same 16 kHz samples).  Checks the parts that real audio stresses and synthetic noise does
+    not: the 1e-10 floor / max-8 clamp on exact silence and a per-clip max set by a short loud segment."""
+    import os
+    from scipy.signal import resample_poly
+    from conftest import GOLDEN
+    from oracle import mel as omel
+    from qasr.model import load_wav
+    eng, sd = full
+    pcm24, rate = load_wav(os.path.join(GOLDEN, "test_audio.wav"))
+    assert rate == 24000
+    pcm = resample_poly(pcm24.astype(np.float64), 2, 3).astype(np.float32)[: 16000 * 6 + 16000 * 3]   # 0-9 s: silence + speech
+    pcm = pcm[16000 * 4:]                                                                            # 4-9 s (speech at 1.2-4.3 s)
+    assert pcm.shape[0] == 80000                                                                      # configs[0]: 5 s clip
+    ref_mel = omel.log_mel(pcm)
+    got_mel = eng.mel(pcm)
+    assert got_mel.shape == (128, 500)
+    assert np.abs(got_mel - ref_mel).max() < 1e-4
+    assert np.isclose(got_mel.min(), ref_mel.min(), atol=1e-6)            # the clamp floor (silent frames) matches
+    model = pipeline.OracleModel(sd, C.AUDIO_SMALL, C.TEXT_SMALL, C.TOKENS, P.DEVICE)
+    with torch.no_grad():
+        emb = model.encode(ref_mel)
+        got = eng.encode(ref_mel)
+        assert got.shape == (65, 1024)                                    # 5 s -> 65 audio tokens, prompt 81
+        assert np.linalg.norm(got - P.bf16_round(emb).numpy()) / np.linalg.norm(emb.numpy()) < 1e-2
+    toks = eng.transcribe_batch([pcm], max_tokens=4, ignore_eos=True)[0]
+    assert len(toks) == 4
