@@ -21,10 +21,14 @@ void embed_splice_launch(const int* ids, const int* audio_src, const bf16_t* emb
 void gather_rows_launch(const bf16_t* src, const int* row_idx, bf16_t* dst, int n, int H, hipStream_t s);
 
 // ---- prefill -------------------------------------------------------------------------------------
-struct KVLayout {          // one layer's cache: K/V [slot][kv_head][max_ctx][hd] bf16
-    bf16_t* k;
-    bf16_t* v;
+struct KVLayout {          // one layer's cache, bf16, per (slot, kv head) a block of max_ctx * hd elements
+    bf16_t* k;             // keys [slot][kv_head][max_ctx][hd]
+    bf16_t* v;             // values in the same row-major form: PROMPT-PASS SCRATCH shared by all layers (qk_norm_rope
+                           // writes it, v_transpose reads it back in the same layer); decode never touches it
     int max_ctx, kv_heads, hd;
+    // the values the decode sweep reads: MFMA-fragment order [key/32][d/16][lane 64][8], see vfrag_index() in
+    // dec_kernels.hip; written by v_transpose (prompt) and decode_attention (append)
+    bf16_t* vf = nullptr;
     __host__ __device__ long off(int slot, int kvh, int pos) const {
         return (((long)slot * kv_heads + kvh) * max_ctx + pos) * hd;
     }
@@ -64,6 +68,8 @@ int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s);
 int decode_gemv_blocks(DecEpi epi, int N);
 // Decode-step form with the RMSNorm of the input fused into the activation staging (norm_w != null):
 // out = epi( rmsnorm(X) . W^T ).  `norm_scratch` [B][K] is only used by the generic fallback.
+// diagnostic: the tuned kernels stamp their phases into dbg[(workgroup*16 + wave)*8 + i] (100 MHz clock); null = off
+void decode_gemv_set_debug(unsigned long long* dbg);
 int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* norm_w, float eps, bf16_t* norm_scratch,
                              hipStream_t s);
 
@@ -81,7 +87,8 @@ void pack_mfma_a_launch(const bf16_t* src, bf16_t* dst, int N, int K, hipStream_
 // attention of the rep = heads/kv_heads query heads over the cache (f32 softmax), out [B][heads*hd].
 void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int heads, int kv_heads, int hd,
                              const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
-                             const float* rope_sin, KVLayout cache, bf16_t* out, hipStream_t s);
+                             const float* rope_sin, KVLayout cache, bf16_t* out, hipStream_t s,
+                             unsigned long long* dbg = nullptr);   // dbg: diagnostic phase stamps, null in product launches
 
 // Greedy bookkeeping after the LM head (Qwen3ASR.swift:336-388): argmax over the per-block partials
 // (lowest index wins ties, like MLX argMax), append the token unless the row is finished, mark EOS /

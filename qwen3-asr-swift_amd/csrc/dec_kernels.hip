@@ -168,6 +168,18 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(KVLayout cache, const 
         for (int q = 0; q < 8; ++q) oe[q] = tile[ch * 8 + q][d];
         *reinterpret_cast<uint4*>(dst + (long)d * vt_stride + ch * 8) = o;
     }
+    if (!cache.vf) return;
+    // the decode sweep's fragment-major image (vfrag_index): 2 chunks of 32 keys, one 16-byte fragment per thread
+    constexpr int DT = HD / 16;
+    bf16_t* vf = cache.vf + cache.off(sl, kvh, 0) + (long)(p0 / 32) * DT * 512;
+    for (int i = tid; i < 2 * DT * 64; i += 256) {
+        const int kbl = i / (DT * 64), rem = i - kbl * DT * 64, dt = rem >> 6, ln = rem & 63, d = dt * 16 + (ln & 15), g = ln >> 4;
+        uint4 o;
+        bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oe[e] = tile[kbl * 32 + (e >> 2) * 16 + g * 4 + (e & 3)][d];
+        *reinterpret_cast<uint4*>(vf + (long)i * 8) = o;
+    }
 }
 
 void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads, int hd,
@@ -575,10 +587,14 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(DecGemvArgs a) {
 // ------------------------------------------------------------------------------------------------
 enum DecPro { DEC_PRO_COPY = 0, DEC_PRO_RMSNORM = 1 };
 
+#ifndef QASR_DIAG_STAMPS
+#define QASR_DIAG_STAMPS 0     // 1 compiles the in-kernel phase stamps (100 MHz wall clock) into the decode kernels:
+#endif                         // diagnostic builds only (make DIAG=1); they cost the product path ~0.4 us per launch
 struct DecGemv2Args {
     DecGemvArgs g;
     const bf16_t* norm_w;      // RMSNORM prologue: weight [K]
     float eps;
+    unsigned long long* dbg;   // diagnostic phase stamps (see decode_gemv_stamps), null in product launches
 };
 
 template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI>
@@ -601,20 +617,32 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     // thread -> (row srow, column chunks scol + TPR*i): a row lives on TPR adjacent lanes of one wave, so
     // its sum of squares needs log2(TPR) shuffles and no LDS round trip
     const int srow = tid / TPR, scol = tid % TPR;
+#if QASR_DIAG_STAMPS
+#define QASR_STAMP(i) do { if (a2.dbg && lane == 0) a2.dbg[((long)blockIdx.x * 16 + wave) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define QASR_STAMP(i) do { } while (0)
+#endif
+    QASR_STAMP(0);
     uint4 xr[XI];
     auto issue_x = [&](int r0) {
         // unconditional loads (clamped row), zeroed afterwards by a select: no branch, no per-load drain
-        const bool live = r0 + srow < a.B;
-        const bf16_t* xp = a.X + (long)(live ? r0 + srow : 0) * K + scol * 8;
+        const bf16_t* xp = a.X + (long)(r0 + srow < a.B ? r0 + srow : 0) * K + scol * 8;
 #pragma unroll
         for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
-        if (!live) {
+    };
+    // Zeroing right after the loads makes the wait for X precede the weight loads on purpose: measured in the real
+    // decode step (cold weights from HBM), issuing the weight stream -- or even just the norm weights -- ahead of that
+    // wait is SLOWER (decode 149.3 -> 157.6 / 151.1 ms at B=32) although a warm-cache probe of the kernel alone gets
+    // faster: the L1 returns data in order across the waves of a CU, so early HBM misses delay the other waves' X.
+    auto mask_x = [&](int r0) {
+        if (r0 + srow >= a.B) {
 #pragma unroll
             for (int i = 0; i < XI; ++i) xr[i] = make_uint4(0, 0, 0, 0);
         }
     };
-    // ---- 1. activation loads first (older in the in-order return queue), then ALL weight fragments ----
+    // ---- 1. activation loads, then (once they are back, see mask_x) ALL weight fragments ------------------
     issue_x(0);
+    mask_x(0);
     uint4 w[NT][KSW];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -641,11 +669,13 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    QASR_STAMP(1);
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         if (ph > 0) {
             __syncthreads();                                      // previous phase's LDS reads are done
             issue_x(ph * RPP);
+            mask_x(ph * RPP);
         }
         // ---- 2. activation rows -> LDS (the weight loads stay in flight) -------------------------------
         char* xrow = s_x + (size_t)srow * XSTRIDE + scol * 16;
@@ -675,7 +705,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
 #pragma unroll
             for (int i = 0; i < XI; ++i) *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = xr[i];
         }
+        if (ph == 0) QASR_STAMP(2);
         __syncthreads();
+        if (ph == 0) QASR_STAMP(3);
         // ---- 3. MFMA: register-resident weights x LDS activations --------------------------------------
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
@@ -691,6 +723,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
             }
         }
     }
+    QASR_STAMP(4);
     // ---- 4. cross-wave reduction in fixed order, epilogue on wave 0 ------------------------------------
     if (wave > 0) {
 #pragma unroll
@@ -700,6 +733,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
                 *reinterpret_cast<f32x4*>(&s_red[((size_t)(wave - 1) * NT * NB + t * NB + b) * 256 + lane * 4]) = acc[t][b];
     }
     __syncthreads();
+    QASR_STAMP(5);
     if (wave != 0) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -710,6 +744,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
                 acc[t][b] += *reinterpret_cast<const f32x4*>(&s_red[((size_t)wv * NT * NB + t * NB + b) * 256 + lane * 4]);
     if constexpr (EPI == DEC_EPI_RESID) dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc, rsd);
     else dec_epilogue<NT, NB, EPI>(a, acc, n0, fr, fc);
+    QASR_STAMP(6);
+#undef QASR_STAMP
 }
 
 // Fragment-major repack of a row-major [N][K] weight for v_mfma_f32_16x16x32_bf16 A operands:
@@ -831,11 +867,13 @@ static bool gemv2_k(const DecGemv2Args& a2, hipStream_t s) {
 
 // Fused form used by the decode step: optional RMSNorm prologue (norm_w != null) + epilogue.
 // Falls back to [rmsnorm_rows +] the generic kernel for shapes without a tuned instantiation.
+static unsigned long long* g_gemv_dbg = nullptr;
+void decode_gemv_set_debug(unsigned long long* dbg) { g_gemv_dbg = dbg; }
 int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* norm_w, float eps, bf16_t* norm_scratch,
                              hipStream_t s) {
     if (a.B <= 0) return 0;
     const int nt = dec_nt(epi, a.N);
-    DecGemv2Args a2{a, norm_w, eps};
+    DecGemv2Args a2{a, norm_w, eps, g_gemv_dbg};
     bool ok = false;
     if (a.Wp && a.N % (16 * nt) == 0 && a.B <= 64) {
         if (norm_w) {
@@ -1013,7 +1051,6 @@ static int lmh_grid() {
     static const int g = getenv("QASR_LMH_GRID") ? atoi(getenv("QASR_LMH_GRID")) : 256;
     return g;
 }
-constexpr int LMH_GRID = 256;
 
 template <int K, int NB>
 static void lm_head_go(const LmHeadArgs& a, hipStream_t s) {
@@ -1057,204 +1094,270 @@ int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf1
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decode attention: one workgroup per (kv head, batch row), 8 waves.  Phase 1: waves 0..rep-1 norm +
-// rope their query head, wave rep does the new key, wave rep+1 copies the new value; K/V are appended
-// to the cache.  Phase 2: waves stream the cached keys/values -- a wave instruction covers 64/CPR
-// consecutive rows (CPR = hd/8 chunks of 16 bytes per row, i.e. 1 KiB contiguous for hd = 128) --
-// every lane keeps an online-softmax state for the rows of its slot and its 8 head dims; the states
-// are merged across slots (shuffles) and waves (LDS) at the end.  Softmax stays in f32.
+// Decode attention on the matrix cores.  One workgroup per (kv head, batch row); a wave owns 32-key
+// chunks of the context (chunk = wave, wave + WAVES, ...), all of whose loads are issued up front:
+//   S^T = K Q^T   16x16x32 MFMA, A = 16 cached key rows straight from HBM (natural [key][hd] layout),
+//                 B = the two query heads of this kv head in columns 0/1 (other columns zero);
+//                 the accumulator puts keys (lane>>4)*4+j of query (lane&15) on a lane, which IS the
+//                 A-operand layout of the next MFMA, so P never leaves registers;
+//   O  += P V     16x16x32 MFMA over the chunk's 32 keys, B = V in the fragment-major cache image
+//                 (KVLayout::vf), one 16-byte load per lane and d tile.
+// Every wave norms + ropes the two query rows itself (no workgroup barrier before the sweep); the
+// token's own key / value are computed by the last two waves, appended to the caches and folded in
+// at the cross-wave merge.  Softmax statistics stay in f32; P is rounded to bf16 like the prompt pass.
 // ------------------------------------------------------------------------------------------------
-template <int HD, int REP, int DA_UNR, int DA_WAVES>
-__global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_kernel(
+template <int HD>
+__device__ __forceinline__ long vfrag_index(int key, int d) {
+    // fragment-major V: [key/32][d/16][lane = (d%16) + 16*g][e = half*4 + j],  key%32 = half*16 + g*4 + j
+    constexpr int DT = HD / 16;
+    const int kb = key >> 5, r = key & 31, half = r >> 4, g = (r & 15) >> 2, j = r & 3;
+    return (((long)kb * DT + (d >> 4)) * 64 + (d & 15) + 16 * g) * 8 + half * 4 + j;
+}
+
+template <int HD, int WAVES, int UNR, bool SPEC>
+__global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     const bf16_t* __restrict__ qkv, const int* __restrict__ ctx_len, int heads, int kv_heads,
     const bf16_t* __restrict__ qn_w, const bf16_t* __restrict__ kn_w, float eps, const float* __restrict__ rope_cos,
-    const float* __restrict__ rope_sin, KVLayout cache, bf16_t* __restrict__ out, float scale) {
-    constexpr int CPR = HD / 8, KPI = 64 / CPR, HALF = HD / 2;
-    __shared__ float s_q[REP][HD];
-    __shared__ float s_kn[HD];
-    __shared__ float s_vn[HD];
-    __shared__ float s_m[DA_WAVES][REP], s_l[DA_WAVES][REP];
-    __shared__ float s_o[DA_WAVES][REP][HD];
+    const float* __restrict__ rope_sin, KVLayout cache, bf16_t* __restrict__ out, float scale,
+    unsigned long long* __restrict__ dbg) {
+    constexpr int REP = 2, KS = HD / 32, DT = HD / 16, HALF = HD / 2;
+#if QASR_DIAG_STAMPS
+#define QASR_STAMP(i) do { if (dbg && (threadIdx.x & 63) == 0) dbg[((blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define QASR_STAMP(i) do { } while (0)
+#endif
+    QASR_STAMP(0);
+    __shared__ __attribute__((aligned(16))) bf16_t s_q[WAVES][REP][HD];      // wave-private query image
+    __shared__ float s_m[WAVES][REP], s_l[WAVES][REP];
+    __shared__ float s_o[WAVES][REP][HD];
+    __shared__ float s_new[REP], s_vn[HD];
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane % CPR, slot = lane / CPR;
-    const bf16_t* kb = cache.k + cache.off(b, kvh, 0) + c * 8;
-    const bf16_t* vb = cache.v + cache.off(b, kvh, 0) + c * 8;
-    // ---- phase 0: the first DA_UNR row groups of every wave go in flight before anything else.  They need
-    // no position (rows are clamped to the allocation and masked later), so the HBM latency of the first
-    // groups hides the dependent loads of phase 1 (ctx_len -> rope table, qkv row, norm weights).
-    uint4 ku[DA_UNR], vu[DA_UNR];
-    auto issue = [&](int g0) {
+    const int fr = lane & 15, g = lane >> 4;
+    const bf16_t* kb = cache.k + cache.off(b, kvh, 0) + g * 8;
+    const bf16_t* vfb = cache.vf + cache.off(b, kvh, 0) + lane * 8;
+    const int max_chunk = cache.max_ctx / 32 - 1;
+    uint4 kreg[UNR][2 * KS], vreg[UNR][DT];
+    auto issue = [&](int chunk0) {
 #pragma unroll
-        for (int u = 0; u < DA_UNR; ++u) {
-            int key = (g0 + u * DA_WAVES) * KPI + slot;
-            key = key < cache.max_ctx ? key : cache.max_ctx - 1;
-            ku[u] = *reinterpret_cast<const uint4*>(kb + (long)key * HD);
-            vu[u] = *reinterpret_cast<const uint4*>(vb + (long)key * HD);
+        for (int u = 0; u < UNR; ++u) {
+            int ch = chunk0 + u * WAVES;
+            ch = ch < max_chunk ? ch : max_chunk;                        // clamped to the allocation, masked later
+            const bf16_t* kr = kb + ((long)ch * 32 + fr) * HD;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                vreg[u][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch * DT + dt) * 512);
         }
     };
-    issue(wave);
-    const int pos = ctx_len[b];
+    int pos;
+    if (SPEC) {
+        issue(wave);                         // before the position is known: rows past it are masked
+        pos = ctx_len[b];
+    } else {
+        pos = ctx_len[b];
+        if (wave * 32 < pos) issue(wave);
+    }
+    const int nchunks = (pos + 31) >> 5;
     const int nh = heads + 2 * kv_heads;
     const bf16_t* row = qkv + (long)b * nh * HD;
-    // ---- phase 1 -------------------------------------------------------------------------------
-    if (wave <= REP) {
-        const bool isq = wave < REP;
-        const bf16_t* src = row + (long)(isq ? kvh * REP + wave : heads + kvh) * HD;
-        const bool act = lane < HALF;
-        float x1 = act ? bf16_to_f32(src[lane]) : 0.0f, x2 = act ? bf16_to_f32(src[lane + HALF]) : 0.0f;
-        const float inv = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)HD + eps);
-        if (act) {
-            const bf16_t* nw = isq ? qn_w : kn_w;
-            float o1, o2;
-            // rope_cos / rope_sin are per-batch-row rows for the CURRENT position (written by the previous
-            // greedy_finalize), so this load does not depend on the ctx_len load
-            norm_rope_pair(x1, x2, bf16_to_f32(nw[lane]), bf16_to_f32(nw[lane + HALF]), inv,
-                           rope_cos[(long)b * HALF + lane], rope_sin[(long)b * HALF + lane], o1, o2);
-            if (isq) {
-                s_q[wave][lane] = o1;
-                s_q[wave][lane + HALF] = o2;
-            } else {
-                s_kn[lane] = o1;
-                s_kn[lane + HALF] = o2;
-                bf16_t* dk = cache.k + cache.off(b, kvh, pos);
-                dk[lane] = f32_to_bf16(o1);
-                dk[lane + HALF] = f32_to_bf16(o2);
-            }
-        }
-    } else if (wave == REP + 1) {
-        const bf16_t* src = row + (long)(heads + kv_heads + kvh) * HD;
-        bf16_t* dv = cache.v + cache.off(b, kvh, pos);
-        for (int i = lane; i < HD; i += 64) {
-            bf16_t v = src[i];
-            s_vn[i] = bf16_to_f32(v);
-            dv[i] = v;
-        }
-    }
-    __syncthreads();
-    // ---- phase 2: cached rows [0, pos) from HBM, the new row from LDS ----------------------------------
-    float q[REP][8];
-#pragma unroll
-    for (int r = 0; r < REP; ++r)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q[r][j] = s_q[r][c * 8 + j];
-    float m[REP], l[REP], o[REP][8];
-#pragma unroll
-    for (int r = 0; r < REP; ++r) {
-        m[r] = -INFINITY;
-        l[r] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[r][j] = 0.0f;
-    }
-    auto absorb = [&](const float (&kf)[8], const float (&vf)[8], bool valid) {
+    // ---- the two query heads: norm + rope on every wave, bf16 image in this wave's LDS slice ------------
+    const bool act = lane < HALF;
+    const float rc = act ? rope_cos[(long)b * HALF + lane] : 0.0f, rs = act ? rope_sin[(long)b * HALF + lane] : 0.0f;
+    float qa[REP][2];
+    {
+        const float w1 = act ? bf16_to_f32(qn_w[lane]) : 0.0f, w2 = act ? bf16_to_f32(qn_w[lane + HALF]) : 0.0f;
+        float x1[REP], x2[REP];
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
-            float d = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d = fmaf(q[r][j], kf[j], d);
-#pragma unroll
-            for (int ofs = 1; ofs < CPR; ofs <<= 1) d += __shfl_xor(d, ofs, 64);
-            const float sc = valid ? d * scale : -INFINITY;
-            const float m_new = fmaxf(m[r], sc);
-            const float m_ref = m_new == -INFINITY ? 0.0f : m_new;
-            const float alpha = expf(m[r] - m_ref), p = expf(sc - m_ref);
-            l[r] = l[r] * alpha + p;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[r][j] = fmaf(p, vf[j], o[r][j] * alpha);
-            m[r] = m_new;
+            const bf16_t* src = row + (long)(kvh * REP + r) * HD;
+            x1[r] = act ? bf16_to_f32(src[lane]) : 0.0f;
+            x2[r] = act ? bf16_to_f32(src[lane + HALF]) : 0.0f;
         }
-    };
-    const int ngroups = (pos + KPI - 1) / KPI;
-    for (int g0 = wave; g0 < ngroups; g0 += DA_WAVES * DA_UNR) {
-        if (g0 != wave) issue(g0);                                  // the first groups are already in flight
 #pragma unroll
-        for (int u = 0; u < DA_UNR; ++u) {
-            if (g0 + u * DA_WAVES < ngroups) {                      // wave-uniform
-                const bool valid = (g0 + u * DA_WAVES) * KPI + slot < pos;
-                float kf[8], vf[8];
-                const bf16_t* ke = reinterpret_cast<const bf16_t*>(&ku[u]);
-                const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vu[u]);
+        for (int r = 0; r < REP; ++r) {
+            const float inv = rsqrtf(wave_sum(x1[r] * x1[r] + x2[r] * x2[r]) / (float)HD + eps);
+            norm_rope_pair(x1[r], x2[r], w1, w2, inv, rc, rs, qa[r][0], qa[r][1]);
+            if (act) {
+                s_q[wave][r][lane] = f32_to_bf16(qa[r][0]);
+                s_q[wave][r][lane + HALF] = f32_to_bf16(qa[r][1]);
+            }
+        }
+    }
+    // ---- the token's own key (wave WAVES-1) and value (wave WAVES-2): cache append + merge terms -------
+    if (wave == WAVES - 1) {
+        const bf16_t* src = row + (long)(heads + kvh) * HD;
+        const float x1 = act ? bf16_to_f32(src[lane]) : 0.0f, x2 = act ? bf16_to_f32(src[lane + HALF]) : 0.0f;
+        const float inv = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)HD + eps);
+        float k1, k2;
+        norm_rope_pair(x1, x2, act ? bf16_to_f32(kn_w[lane]) : 0.0f, act ? bf16_to_f32(kn_w[lane + HALF]) : 0.0f, inv, rc, rs, k1, k2);
+        if (act) {
+            bf16_t* dk = cache.k + cache.off(b, kvh, pos);
+            dk[lane] = f32_to_bf16(k1);
+            dk[lane + HALF] = f32_to_bf16(k2);
+        }
 #pragma unroll
-                // rows beyond the context were read from unwritten cache memory: zero them (p = 0 would still
-                // turn a stale NaN/Inf into NaN through 0 * x)
-                for (int j = 0; j < 8; ++j) {
-                    kf[j] = valid ? bf16_to_f32(ke[j]) : 0.0f;
-                    vf[j] = valid ? bf16_to_f32(ve[j]) : 0.0f;
+        for (int r = 0; r < REP; ++r) {
+            const float d = wave_sum(act ? qa[r][0] * k1 + qa[r][1] * k2 : 0.0f);
+            if (lane == 0) s_new[r] = d * scale;
+        }
+    } else if (wave == WAVES - 2) {
+        const bf16_t* src = row + (long)(heads + kv_heads + kvh) * HD;
+        bf16_t* dvf = cache.vf + cache.off(b, kvh, 0);
+        for (int i = lane; i < HD; i += 64) {
+            const bf16_t v = src[i];
+            s_vn[i] = bf16_to_f32(v);
+            dvf[vfrag_index<HD>(pos, i)] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    mfma_bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (fr < REP) u = *reinterpret_cast<const uint4*>(&s_q[wave][fr][ks * 32 + g * 8]);
+        qf[ks] = __builtin_bit_cast(mfma_bf16x8, u);
+    }
+    QASR_STAMP(1);
+    // ---- sweep -------------------------------------------------------------------------------------
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    for (int c0 = wave; c0 < nchunks; c0 += WAVES * UNR) {
+        if (c0 != wave) issue(c0);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int chunk = c0 + u * WAVES;
+            if (chunk < nchunks) {                                       // wave-uniform
+                f32x4 sc[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, kreg[u][h * KS + ks]), qf[ks], acc, 0, 0, 0);
+                    sc[h] = acc;
                 }
-                absorb(kf, vf, valid);
+                const int key0 = chunk * 32 + g * 4;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = key0 + h * 16 + j < pos ? sc[h][j] * scale : -INFINITY;   // select: stale rows may be NaN
+                        sc[h][j] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);                    // finite: a chunk below nchunks has a valid key
+                const float alpha = __expf(m_run - m_new);
+                float rsum = 0.0f;
+                unsigned pk[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const bf16_t p0 = f32_to_bf16(__expf(sc[h][j] - m_new)), p1 = f32_to_bf16(__expf(sc[h][j + 1] - m_new));
+                        rsum += bf16_to_f32(p0) + bf16_to_f32(p1);
+                        pk[h * 2 + j / 2] = (unsigned)p0 | ((unsigned)p1 << 16);
+                    }
+                l_run = l_run * alpha + rsum;
+                m_run = m_new;
+                const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), 0));
+                const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), 1));
+                uint4 vv[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) vv[dt] = vreg[u][dt];
+                if (chunk * 32 + 32 > pos) {                             // partial chunk: stale V rows would give 0 * NaN
+                    unsigned msk[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int k_lo = key0 + (w >> 1) * 16 + (w & 1) * 2;
+                        msk[w] = (k_lo < pos ? 0x0000ffffu : 0u) | (k_lo + 1 < pos ? 0xffff0000u : 0u);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) { vv[dt].x &= msk[0]; vv[dt].y &= msk[1]; vv[dt].z &= msk[2]; vv[dt].w &= msk[3]; }
+                }
+                const mfma_bf16x8 pa = __builtin_bit_cast(mfma_bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    o[dt][0] *= a0;
+                    o[dt][1] *= a1;
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, __builtin_bit_cast(mfma_bf16x8, vv[dt]), o[dt], 0, 0, 0);
+                }
             }
         }
     }
-    if (wave == DA_WAVES - 1) {      // the token's own key/value (slot 0 lanes only)
-        float kf[8], vf[8];
+    QASR_STAMP(2);
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (lane < REP) { s_m[wave][lane] = m_run; s_l[wave][lane] = l_run; }
+    if (g == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[j] = s_kn[c * 8 + j]; vf[j] = s_vn[c * 8 + j]; }
-        absorb(kf, vf, slot == 0);
-    }
-    // merge the KPI slots of this wave (lanes with equal c)
-#pragma unroll
-    for (int r = 0; r < REP; ++r) {
-#pragma unroll
-        for (int ofs = CPR; ofs < 64; ofs <<= 1) {
-            const float mo = __shfl_xor(m[r], ofs, 64), lo = __shfl_xor(l[r], ofs, 64);
-            const float m_new = fmaxf(m[r], mo);
-            const float m_ref = m_new == -INFINITY ? 0.0f : m_new;
-            const float a0 = expf(m[r] - m_ref), a1 = expf(mo - m_ref);
-            l[r] = l[r] * a0 + lo * a1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float oo = __shfl_xor(o[r][j], ofs, 64);
-                o[r][j] = o[r][j] * a0 + oo * a1;
-            }
-            m[r] = m_new;
-        }
-        if (slot == 0) {
-            if (c == 0) { s_m[wave][r] = m[r]; s_l[wave][r] = l[r]; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s_o[wave][r][c * 8 + j] = o[r][j];
+        for (int dt = 0; dt < DT; ++dt) {
+            s_o[wave][0][dt * 16 + fr] = o[dt][0];
+            s_o[wave][1][dt * 16 + fr] = o[dt][1];
         }
     }
+    QASR_STAMP(3);
+    QASR_STAMP(4);
     __syncthreads();
-    // merge waves: thread t < REP*HD owns one output element
-    for (int i = tid; i < REP * HD; i += DA_WAVES * 64) {
+    QASR_STAMP(5);
+    // merge waves + the token's own key/value: thread t < REP*HD owns one output element
+    for (int i = tid; i < REP * HD; i += WAVES * 64) {
         const int r = i / HD, d = i - r * HD;
-        float mm = -INFINITY;
+        float mm = s_new[r];
 #pragma unroll
-        for (int w = 0; w < DA_WAVES; ++w) mm = fmaxf(mm, s_m[w][r]);
-        float num = 0.0f, den = 0.0f;
+        for (int w = 0; w < WAVES; ++w) mm = fmaxf(mm, s_m[w][r]);
+        const float pn = __expf(s_new[r] - mm);
+        float num = pn * s_vn[d], den = pn;
 #pragma unroll
-        for (int w = 0; w < DA_WAVES; ++w) {
-            const float a = s_m[w][r] == -INFINITY ? 0.0f : expf(s_m[w][r] - mm);
-            num += s_o[w][r][d] * a;
-            den += s_l[w][r] * a;
+        for (int w = 0; w < WAVES; ++w) {
+            const float mw = s_m[w][r];
+            if (mw != -INFINITY) {                                       // waves without a chunk left s_o unwritten
+                const float a = __expf(mw - mm);
+                num += s_o[w][r][d] * a;
+                den += s_l[w][r] * a;
+            }
         }
         out[(long)b * heads * HD + (long)(kvh * REP + r) * HD + d] = f32_to_bf16(num / den);
     }
+    QASR_STAMP(6);
+#undef QASR_STAMP
 }
 
 void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int heads, int kv_heads, int hd,
                              const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
-                             const float* rope_sin, KVLayout cache, bf16_t* out, hipStream_t s) {
+                             const float* rope_sin, KVLayout cache, bf16_t* out, hipStream_t s, unsigned long long* dbg) {
     if (B <= 0) return;
-    const int rep = heads / kv_heads;
+    if (heads != 2 * kv_heads) throw std::invalid_argument("decode attention: built for 2 query heads per kv head");
+    if (!cache.vf) throw std::invalid_argument("decode attention: the fragment-major V image is not allocated");
+    if (cache.max_ctx % 32) throw std::invalid_argument("decode attention: cache capacity must be a multiple of 32 keys");
     const float scale = 1.0f / sqrtf((float)hd);
     dim3 grid(kv_heads, B);
-    static const int unr = getenv("QASR_DA_UNR") ? atoi(getenv("QASR_DA_UNR")) : 2;      // tuning knobs (A/B)
-    static const int nw = getenv("QASR_DA_WAVES") ? atoi(getenv("QASR_DA_WAVES")) : 16;
-#define QASR_DA_GO(HD_, UNR_, W_)                                                                                   \
-    hipLaunchKernelGGL((decode_attention_kernel<HD_, 2, UNR_, W_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, \
-                       kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale)
-    if (hd == 128 && rep == 2) {
-        if (nw == 16 && unr == 2) QASR_DA_GO(128, 2, 16);
-        else if (nw == 16 && unr == 3) QASR_DA_GO(128, 3, 16);
-        else if (nw == 16) QASR_DA_GO(128, 4, 16);
-        else if (unr == 2) QASR_DA_GO(128, 2, 8);
-        else if (unr == 8) QASR_DA_GO(128, 8, 8);
-        else QASR_DA_GO(128, 4, 8);
-    } else if (hd == 32 && rep == 2) {
-        QASR_DA_GO(32, 2, 8);
+    // A/B knobs: waves per workgroup (8 with two chunks in flight per wave | 16 with one) and speculative first loads
+    static const int nw = getenv("QASR_DA_WAVES") ? atoi(getenv("QASR_DA_WAVES")) : 8;
+    static const int spec = getenv("QASR_DA_SPEC") ? atoi(getenv("QASR_DA_SPEC")) : 0;
+#define QASR_DAM_GO(HD_, W_, U_, S_)                                                                                         \
+    hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, kv_heads, \
+                       qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg)
+    if (hd == 128) {
+        if (nw == 16 && spec) QASR_DAM_GO(128, 16, 1, true);
+        else if (nw == 16) QASR_DAM_GO(128, 16, 1, false);
+        else if (spec) QASR_DAM_GO(128, 8, 2, true);
+        else QASR_DAM_GO(128, 8, 2, false);
+    } else if (hd == 32) {
+        QASR_DAM_GO(32, 8, 1, false);
     } else
-        throw std::invalid_argument("decode attention: unsupported (head_dim, heads/kv_heads)");
+        throw std::invalid_argument("decode attention: unsupported head_dim");
+#undef QASR_DAM_GO
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,7 +5,9 @@
 // QuantizedTextDecoder.swift / FloatTextDecoder.swift (model), PreQuantizedEmbedding.swift:35-49.
 //
 // HBM layout (per engine):
-//   KV cache   bf16 [layer] x { K, V } [slot][kv_head][max_ctx][head_dim]   static, appended in place
+//   K cache    bf16 [layer][slot][kv_head][max_ctx][head_dim]               static, appended in place
+//   V cache    bf16 [layer][slot][kv_head][max_ctx/32][head_dim/16][64][8]  MFMA-fragment order (vfrag_index), appended in place
+//   V rows     bf16 [slot][kv_head][max_ctx][head_dim]                      prompt pass only (one layer live)
 //   V^T        bf16 [slot][kv_head][head_dim][vt_stride]                    prompt pass only (one layer live)
 //   prompt pass activations are packed over all clips: row p = cu[clip] + position
 //   decode activations are [batch row][features]
@@ -14,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 
 namespace qasr {
 
@@ -125,13 +128,14 @@ void Engine::finalize_decoder() {
     }
     const int B = cfg_.max_batch, nh = cfg_.heads + 2 * cfg_.kv_heads;
     kcache_.clear();
-    vcache_.clear();
+    vfcache_.clear();
     const size_t cache_bytes = (size_t)B * cfg_.kv_heads * max_ctx_ * hd * sizeof(bf16_t);
+    d_vrows_.alloc(cache_bytes);          // row-major V of the layer in flight (prompt pass only)
     for (int i = 0; i < cfg_.dec_layers; ++i) {
         kcache_.push_back(std::make_unique<DevBuf>());
-        vcache_.push_back(std::make_unique<DevBuf>());
+        vfcache_.push_back(std::make_unique<DevBuf>());
         kcache_.back()->alloc(cache_bytes);
-        vcache_.back()->alloc(cache_bytes);
+        vfcache_.back()->alloc(cache_bytes);
     }
     d_rope_rows_.alloc((size_t)2 * B * (hd / 2) * sizeof(float));
     QASR_HIP(hipMemsetAsync(d_rope_rows_.p, 0, d_rope_rows_.bytes, stream_));
@@ -268,7 +272,7 @@ void Engine::run_prefill(bool want_logits) {
     embed_splice_launch(d_p_ids_, d_p_audio_src_, decw_.embed, d_audio_.as<bf16_t>(), x, P, H, s);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
-        KVLayout kv{kcache_[l]->as<bf16_t>(), vcache_[l]->as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd};
+        KVLayout kv{kcache_[l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
         rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
         gemm_nt(ADense{h, H, P, H}, L.wqkv, H, P, nh * hd, H, EpiBiasActBf16<0>{qkv, (long)nh * hd, nullptr}, s);
         qk_norm_rope_launch(qkv, d_p_slot_, d_p_pos_, P, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
@@ -314,9 +318,9 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     const GreedyState gs = greedy_rows(r0);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
-        KVLayout kv{kcache_[l]->as<bf16_t>(), vcache_[l]->as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd};
+        KVLayout kv{kcache_[l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
         kv.k += kv.off(r0, 0, 0);
-        kv.v += kv.off(r0, 0, 0);
+        kv.vf += kv.off(r0, 0, 0);
         DecGemvArgs a{};
         a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
         decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, h, s);
@@ -554,7 +558,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     if (!finalized_ || batch_ <= 0) throw std::runtime_error("kernel_probe needs a prepared batch");
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
     const DecLayerW& L = decw_.layers[0];
-    KVLayout kv{kcache_[0]->as<bf16_t>(), vcache_[0]->as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd};
+    KVLayout kv{kcache_[0]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[0]->as<bf16_t>()};
     hipStream_t s = stream_;
     std::vector<int> ctx(batch_);
     QASR_HIP(hipMemcpy(ctx.data(), gstate_.ctx_len, batch_ * sizeof(int), hipMemcpyDeviceToHost));
@@ -622,6 +626,59 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         (void)hipEventDestroy(e1);
     }
     *avg_ms = ms / (float)reps;
+    if (which == 1 && getenv("QASR_DA_STAMPS")) {
+        // diagnostic: one launch with phase stamps (100 MHz wall clock), printed as averages over workgroups / waves
+        const int nw = 16, nwg = rows * cfg_.kv_heads;
+        DevBuf d;
+        d.alloc((size_t)nwg * nw * 8 * sizeof(unsigned long long));
+        QASR_HIP(hipMemsetAsync(d.p, 0, d.bytes, s));
+        const RopeRows rr = rope_rows(0);
+        decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn,
+                                cfg_.rms_eps, rr.cos_rows, rr.sin_rows, kv, d_dattn_.as<bf16_t>(), s, d.as<unsigned long long>());
+        std::vector<unsigned long long> h((size_t)nwg * nw * 8);
+        QASR_HIP(hipMemcpyAsync(h.data(), d.p, d.bytes, hipMemcpyDeviceToHost, s));
+        QASR_HIP(hipStreamSynchronize(s));
+        unsigned long long t0 = ~0ull, t6 = 0;
+        for (size_t i = 0; i < h.size(); i += 8) if (h[i]) { t0 = std::min(t0, h[i]); t6 = std::max(t6, h[i + 6]); }
+        double acc[7] = {0}; int cnt = 0;
+        for (size_t i = 0; i < h.size(); i += 8) if (h[i]) { for (int k = 0; k < 7; ++k) acc[k] += (double)(h[i + k] - t0); ++cnt; }
+        fprintf(stderr, "[qasr] attention stamps (us since first wave start, mean over %d waves): entry %.2f | phase1 done %.2f | "
+                "after sync %.2f | sweeps done %.2f | slot merge done %.2f | after sync %.2f | end %.2f | span %.2f\n", cnt,
+                acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100,
+                acc[5] / cnt / 100, acc[6] / cnt / 100, (double)(t6 - t0) / 100);
+    }
+    if (which == 0 && getenv("QASR_GEMV_STAMPS")) {
+        DevBuf d;
+        const size_t n = (size_t)512 * 16 * 8;
+        d.alloc(n * sizeof(unsigned long long));
+        std::vector<unsigned long long> hst(n);
+        const char* names[4] = {"qkv (norm)", "o-proj (resid)", "gate/up (norm, swiglu)", "down (resid)"};
+        for (int k = 0; k < 4; ++k) {
+            QASR_HIP(hipMemsetAsync(d.p, 0, d.bytes, s));
+            DecGemvArgs a{};
+            a.B = rows;
+            decode_gemv_set_debug(d.as<unsigned long long>());
+            if (k == 0) { a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
+                          decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, d_dh_.as<bf16_t>(), s); }
+            if (k == 1) { a.W = L.wo; a.Wp = L.wo_p; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();
+                          decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s); }
+            if (k == 2) { a.W = L.wgu; a.Wp = L.wgu_p; a.X = d_dx_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
+                          decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, d_dh_.as<bf16_t>(), s); }
+            if (k == 3) { a.W = L.wdown; a.Wp = L.wdown_p; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
+                          decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s); }
+            decode_gemv_set_debug(nullptr);
+            QASR_HIP(hipMemcpyAsync(hst.data(), d.p, d.bytes, hipMemcpyDeviceToHost, s));
+            QASR_HIP(hipStreamSynchronize(s));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t i = 0; i < n; i += 8) if (hst[i]) { t0 = std::min(t0, hst[i]); for (int q = 0; q < 7; ++q) t1 = std::max(t1, hst[i + q]); }
+            double acc[7] = {0}; int cnt[7] = {0};
+            for (size_t i = 0; i < n; i += 8) if (hst[i]) for (int q = 0; q < 7; ++q) if (hst[i + q]) { acc[q] += (double)(hst[i + q] - t0); ++cnt[q]; }
+            fprintf(stderr, "[qasr] gemv stamps %-24s (us since first wave, mean over %d waves): entry %.2f | loads issued %.2f | X staged %.2f | "
+                    "after sync %.2f | MFMA done %.2f | after reduce sync %.2f | end(w0) %.2f | span %.2f\n", names[k], cnt[0],
+                    acc[0] / cnt[0] / 100, acc[1] / cnt[1] / 100, acc[2] / cnt[2] / 100, acc[3] / cnt[3] / 100, acc[4] / cnt[4] / 100,
+                    acc[5] / cnt[5] / 100, cnt[6] ? acc[6] / cnt[6] / 100 : 0.0, (double)(t1 - t0) / 100);
+        }
+    }
     double bytes = 0;
     if (which == 0) bytes = 2.0 * ((double)nh * hd * H + (double)H * nq + 2.0 * I * H + (double)H * I);
     else if (which == 1) { for (int b = 0; b < rows; ++b) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)ctx[b]; }

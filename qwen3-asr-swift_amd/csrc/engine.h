@@ -189,7 +189,8 @@ private:
     } decw_;
     int max_prompt_ = 0, max_ctx_ = 0, max_pos_ = 0, vt_stride_ = 0;
     DevBuf d_rope_cos_, d_rope_sin_, d_rope_rows_;    // tables [max_ctx][hd/2]; per-row copies for the next step
-    std::vector<std::unique_ptr<DevBuf>> kcache_, vcache_;     // per layer
+    std::vector<std::unique_ptr<DevBuf>> kcache_, vfcache_;     // per layer: keys row-major, values fragment-major
+    DevBuf d_vrows_;                                            // row-major V of one layer (prompt-pass scratch)
     DevBuf d_vt_;
     DevBuf d_px_, d_ph_, d_pqkv_, d_pqr_, d_pattn_, d_pact_;   // prefill (packed prompt positions)
     DevBuf d_dx_, d_dh_, d_dqkv_, d_dattn_, d_dact_, d_logits_, d_part_val_, d_part_idx_;   // decode rows

@@ -89,7 +89,8 @@ void Engine::unload() {
     tensors_.clear();
     fused_.clear();
     kcache_.clear();
-    vcache_.clear();
+    vfcache_.clear();
+    d_vrows_.release();
     finalized_ = false;
 }
 size_t Engine::memory_footprint() const {
