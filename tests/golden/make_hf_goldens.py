@@ -118,6 +118,42 @@ def main():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_tiny.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items()})
+    aligner_golden(m, out)
+
+
+def aligner_golden(m, enc):
+    """Forced-aligner forward (ForcedAligner.swift:258-299): ONE pass over [template + audio + slotted text] with no
+    cache, final-normed hidden state of every position, then a Linear(hidden, classes) head -- the computation of
+    transformers' Qwen3ASRForTokenClassification (GenericForTokenClassification: `score(hidden_states)`).  Stored:
+    ids, audio features, head weights, hidden states and logits at the timestamp slots."""
+    from oracle.aligner import build_input_ids
+    tok = C.TOKENS_TINY
+    ts_id, n_cls = 506, 40
+    g = torch.Generator().manual_seed(11)
+    slotted, ts_pos = [], []
+    for w in range(9):                       # 9 "words" of 1-3 tokens between timestamp slots
+        ts_pos.append(len(slotted)); slotted.append(ts_id)
+        slotted += [int(v) for v in torch.randint(10, 290, (1 + w % 3,), generator=g)]
+        ts_pos.append(len(slotted)); slotted.append(ts_id)
+    emb = torch.from_numpy(enc["enc_out_300"])
+    n_audio = emb.shape[0]
+    ids, a0 = build_input_ids(slotted, n_audio, tok)
+    lm = m.model.language_model
+    hidden = lm.embed_tokens.weight.shape[1]
+    wc = torch.randn(n_cls, hidden, generator=g) * 0.3
+    bc = torch.randn(n_cls, generator=g) * 0.1
+    with torch.no_grad():
+        x = lm.embed_tokens(torch.tensor([ids])).clone()
+        x[0, a0:a0 + n_audio] = emb
+        h = lm(inputs_embeds=x, use_cache=False).last_hidden_state[0]
+        start = len(ids) - len(slotted)
+        logits = h[[start + p for p in ts_pos]] @ wc.T + bc
+    out = {"ids": np.array(ids, dtype=np.int32), "slotted": np.array(slotted, dtype=np.int32),
+           "ts_pos": np.array(ts_pos, dtype=np.int32), "audio": emb.numpy(), "head_w": wc.numpy(), "head_b": bc.numpy(),
+           "hidden": h.numpy(), "logits": logits.numpy(), "ts_id": np.int32(ts_id)}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_tiny_aligner.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: getattr(v, "shape", ()) for k, v in out.items()})
 
 
 if __name__ == "__main__":
