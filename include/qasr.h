@@ -42,6 +42,7 @@ extern "C" {
 #define QASR_ERR_IO 4           /* checkpoint directory / file problem */
 #define QASR_ERR_CAPACITY 5     /* batch or clip exceeds the engine's configured capacity */
 #define QASR_ERR_EMPTY_AUDIO 6  /* zero-length clip (the reference traps on it) */
+#define QASR_ERR_UNSUPPORTED 7  /* input the reference handles with a closed-source dependency (see qasr_split_words) */
 
 #define QASR_DTYPE_F32 0
 #define QASR_DTYPE_BF16 1
@@ -71,7 +72,13 @@ typedef struct qasr_config {
     int32_t max_batch;                 /* clips per batch */
     int32_t max_audio_seconds;         /* longest clip, seconds at 16 kHz (reference cap: 1200) */
     int32_t max_new_tokens;            /* decoder output cap (reference default 448) */
-    int32_t max_prompt_extra;          /* room for context / language hint tokens in the prompt */
+    int32_t max_prompt_extra;          /* room for context / language hint tokens (aligner: the slotted text) in the prompt */
+    /* forced aligner head (Qwen3ForcedAligner, ForcedAligner.swift:63-83; Configuration.swift:132-133).
+     * classify_num == 0: an ASR engine (tied LM head).  > 0: the checkpoint's `lm_head.{weight,bias}` is a
+     * Linear(hidden, classify_num) over timestamp classes and only the qasr_align* entry points run. */
+    int32_t classify_num;              /* 5000 for Qwen3-ForcedAligner-0.6B */
+    int32_t tok_timestamp;             /* <|timestamp|> = 151705 (Qwen3ASR.swift:62) */
+    float timestamp_segment_time;      /* seconds per class, 0.08 */
 } qasr_config;
 
 typedef struct qasr_options {
@@ -193,6 +200,56 @@ int qasr_prefill_logits(qasr_engine* e, const float* audio_embeds, int n_audio,
                         const qasr_options* opt, float* logits);
 /* teacher-forced steps on slot 0: feeds tokens[i], returns logits [n, vocab]. */
 int qasr_decode_forced(qasr_engine* e, const int32_t* tokens, int n, float* logits);
+
+/* ---- forced aligner ----------------------------------------------------------------------
+ * Replaces Qwen3ForcedAligner.align / alignLong (Sources/Qwen3ASR/ForcedAligner.swift:226-331, :97-180):
+ * mel -> audio encoder -> ONE decoder pass over [chat template + audio + text with <timestamp> slots] (no cache,
+ * no autoregression) -> Linear(hidden, classify_num) at the slots -> argmax -> LIS monotonicity fix-up -> seconds.
+ * Engines are created from the "aligner-0.6B" preset (encoder = the reference's `.forcedAligner` config). */
+typedef struct qasr_aligned_word {     /* AlignedWord (Sources/AudioCommon/Protocols.swift) */
+    const char* text;                  /* surface form: the word with its adjacent punctuation */
+    float start_time, end_time;        /* seconds */
+} qasr_aligned_word;
+
+typedef struct qasr_alignment {        /* owned by the engine, valid until its next align call */
+    const qasr_aligned_word* words;
+    size_t n_words;
+    const int32_t* raw_indices;        /* argmax class per timestamp slot before the fix-up (last pass), 2 per word */
+    size_t n_indices;
+    int32_t passes;                    /* align passes run (qasr_align: 1; qasr_align_long: 1 + re-alignments) */
+} qasr_alignment;
+
+/* TextPreprocessor.splitIntoWordPairs (TextPreprocessing.swift:103-263), default path: whitespace split, one word
+ * per Han ideograph, cleaned form keeps Unicode letters / numbers / marks and the ASCII apostrophe.  *surfaces and
+ * *cleaned receive '\n'-joined UTF-8 (malloc'ed, release with qasr_free); returns the word count, or
+ * -QASR_ERR_UNSUPPORTED for the languages the reference hands to Apple's NLTokenizer (Japanese, Korean, Thai, Lao,
+ * Khmer, Burmese, Tibetan: not reproducible) -- pass pre-split words to qasr_align_words for those.  Pure CPU. */
+int qasr_split_words(const char* text, const char* language, char** surfaces, char** cleaned);
+/* TimestampCorrection.longestIncreasingSubsequencePositions (TimestampCorrection.swift:102-144); returns the count. */
+int qasr_lis_positions(const int32_t* values, size_t n, int32_t* positions);
+/* TimestampCorrection.enforceMonotonicity (TimestampCorrection.swift:15-99); out has n entries.  Pure CPU. */
+int qasr_enforce_monotonicity(const int32_t* raw, size_t n, int32_t* out);
+/* Qwen3ForcedAligner.findTrailingPlateauStart (ForcedAligner.swift:196-215) on the words' start times. */
+int qasr_find_trailing_plateau(const float* start_times, size_t n, float tolerance, int32_t min_size);
+/* TextPreprocessor.prepareForAlignment (TextPreprocessing.swift:48-93) with the engine's tokenizer: token ids with
+ * <timestamp> slots around every word, the slot positions inside ids, and the number of words kept.
+ * Returns the id count or -1 (capacity / unsupported language / no tokenizer). */
+int qasr_align_prepare(qasr_engine* e, const char* text, const char* language, int32_t* ids, int32_t ids_cap,
+                       int32_t* ts_positions, int32_t ts_cap, int32_t* n_ts, int32_t* n_words);
+/* Stage entry point (oracle diffing): forward for already slotted ids -> raw argmax class per slot; logits
+ * (optional) receives [n_ts, classify_num] f32 (bf16 values widened). */
+int qasr_align_raw(qasr_engine* e, const float* pcm, size_t n, const int32_t* slotted_ids, int32_t n_ids,
+                   const int32_t* ts_positions, int32_t n_ts, int32_t* raw_indices, float* logits);
+/* align(audio:text:sampleRate:language:) -- single pass.  16 kHz input (no resampler, as for transcribe). */
+int qasr_align(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* text, const char* language,
+               qasr_alignment* out);
+/* the same with caller-split words (surface + cleaned form per word): the NLTokenizer languages. */
+int qasr_align_words(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* const* surfaces,
+                     const char* const* cleaned, size_t n_words, qasr_alignment* out);
+/* alignLong: re-aligns the remainder while a trailing plateau (>= 5 words within 0.1 s) is detected on audio longer
+ * than 240 s, at most 10 passes (ForcedAligner.swift:97-180). */
+int qasr_align_long(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* text,
+                    const char* language, qasr_alignment* out);
 
 #ifdef __cplusplus
 }

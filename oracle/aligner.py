@@ -284,3 +284,43 @@ def align(model, pcm, pairs, encode, ts_id=TIMESTAMP_TOKEN_ID):
         logits = classify_logits(emb, ids, ts_pos, model.W, model.text_cfg, model.policy, model.tok)
         raw = [dec_mod.argmax_lowest(r) for r in logits]
     return words_from_indices(enforce_monotonicity(raw), words), raw
+
+
+def align_long(align_fn, pcm, text, sample_rate=16000, bypass_s=240.0, min_chunk_s=5.0, plateau_tol=0.1, plateau_min=5):
+    """ForcedAligner.swift:97-180 around a single-pass `align_fn(audio, text) -> [(word, start, end)]`.
+    -> (words, passes)."""
+    f32 = np.float32
+    out, audio, rem_text, offset, passes = [], np.asarray(pcm, dtype=np.float32), text, f32(0), 1
+    while len(audio) and rem_text:
+        duration = f32(len(audio)) / f32(sample_rate)
+        aligned = align_fn(audio, rem_text)
+        if not aligned:
+            break
+
+        def shifted(ws):
+            return [(w, float(f32(s) + offset), float(f32(e) + offset)) for w, s, e in ws] if offset != 0 else list(ws)
+        if duration <= bypass_s or len(aligned) < plateau_min * 2:
+            out += shifted(aligned)
+            break
+        p = find_trailing_plateau_start([s for _, s, _ in aligned], plateau_tol, plateau_min)
+        if p == len(aligned):
+            out += shifted(aligned)
+            break
+        if p == 0:
+            break                                   # (the reference would trap on `reliable.last!`)
+        split_time = f32(aligned[p - 1][2])
+        out += shifted(aligned[:p])
+        split_sample = int(split_time * f32(sample_rate))
+        if split_sample >= len(audio):
+            break
+        nxt = audio[split_sample:]
+        if f32(len(nxt)) / f32(sample_rate) < min_chunk_s:
+            break
+        words_all = [w for w in rem_text.split(" ") if w]
+        if p >= len(words_all):
+            break
+        audio, rem_text, offset = nxt, " ".join(words_all[p:]), f32(offset + split_time)
+        passes += 1
+        if passes > 10:
+            break
+    return out, passes

@@ -56,6 +56,8 @@ class TextDecoderConfig:
 
 AUDIO_SMALL = AudioEncoderConfig()
 AUDIO_LARGE = AudioEncoderConfig(d_model=1024, heads=16, ffn_dim=4096, layers=24, output_dim=2048)
+# Qwen3AudioEncoderConfig.forcedAligner (AudioEncoder.swift:71-88): the large encoder projecting to the 1024-wide decoder
+AUDIO_ALIGNER = AudioEncoderConfig(d_model=1024, heads=16, ffn_dim=4096, layers=24, output_dim=1024)
 TEXT_SMALL = TextDecoderConfig()
 TEXT_SMALL_8BIT = replace(TEXT_SMALL, bits=8)
 TEXT_LARGE = TextDecoderConfig(hidden=2048, inter=6144)

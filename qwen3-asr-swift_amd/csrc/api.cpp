@@ -1,5 +1,6 @@
 // api.cpp -- extern "C" boundary (include/qasr.h).  Exceptions never cross it.
 #include "engine.h"
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,7 +43,8 @@ int qasr_default_config(const char* preset, qasr_config* c) {
     c->tok_user = 872; c->tok_assistant = 77091;
     c->fft_scale = 2.0f;
     c->device = 0; c->max_batch = 32; c->max_audio_seconds = 30; c->max_new_tokens = 448; c->max_prompt_extra = 64;
-    if (p == "tiny") {   // test geometry (oracle/config.py AUDIO_TINY / TEXT_TINY / TOKENS_TINY)
+    c->classify_num = 0; c->tok_timestamp = 151705; c->timestamp_segment_time = 0.08f;
+    if (p == "tiny" || p == "tiny-aligner") {   // test geometry (oracle/config.py AUDIO_TINY / TEXT_TINY / TOKENS_TINY)
         c->enc_d_model = 64; c->enc_heads = 2; c->enc_ffn = 128; c->enc_layers = 2; c->enc_out_dim = 64;
         c->conv_channels = 32; c->n_window_infer = 200;
         c->vocab = 512; c->hidden = 64; c->dec_layers = 2; c->heads = 4; c->kv_heads = 2; c->head_dim = 32; c->inter = 128;
@@ -50,6 +52,18 @@ int qasr_default_config(const char* preset, qasr_config* c) {
         c->tok_audio_pad = 504; c->tok_asr_text = 505; c->tok_newline = 198; c->tok_system = 300;
         c->tok_user = 301; c->tok_assistant = 302;
         c->bits = 16; c->max_batch = 8;
+        if (p == "tiny-aligner") { c->classify_num = 40; c->tok_timestamp = 506; c->max_prompt_extra = 256; c->max_new_tokens = 1; }
+        return QASR_OK;
+    }
+    std::string lower_p = p;
+    for (auto& ch : lower_p) ch = (char)tolower(ch);
+    if (contains(lower_p, "aligner")) {
+        // Qwen3ForcedAligner (ForcedAligner.swift:63-83): encoder = Qwen3AudioEncoderConfig.forcedAligner
+        // (AudioEncoder.swift:71-88: the large encoder projecting to 1024), text decoder = .small, 5000 classes
+        c->enc_d_model = 1024; c->enc_heads = 16; c->enc_ffn = 4096; c->enc_layers = 24; c->enc_out_dim = 1024;
+        c->classify_num = 5000;
+        c->bits = contains(lower_p, "bf16") || contains(lower_p, "float") ? 16 : contains(lower_p, "8bit") ? 8 : 4;   // ForcedAlignerVariant.detect :17-26
+        c->max_batch = 1; c->max_audio_seconds = 300; c->max_new_tokens = 1; c->max_prompt_extra = 4096;
         return QASR_OK;
     }
     // ASRModelSize.detect / detectBits (Qwen3ASR.swift:581-601)
@@ -187,6 +201,140 @@ int qasr_transcribe(qasr_engine* e, const float* pcm, size_t n, int sample_rate,
     out->tokens = e->impl->result_tokens.data();
     out->n_tokens = len;
     return QASR_OK;
+}
+
+// ---- forced aligner ---------------------------------------------------------------------------------
+static char* dup_joined(const std::vector<std::string>& v) {
+    size_t n = 1;
+    for (auto& s : v) n += s.size() + 1;
+    char* out = (char*)malloc(n);
+    if (!out) return nullptr;
+    char* q = out;
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i) *q++ = '\n';
+        std::memcpy(q, v[i].data(), v[i].size());
+        q += v[i].size();
+    }
+    *q = 0;
+    return out;
+}
+
+int qasr_split_words(const char* text, const char* language, char** surfaces, char** cleaned) {
+    if (!text) return -QASR_ERR_INVALID;
+    if (surfaces) *surfaces = nullptr;
+    if (cleaned) *cleaned = nullptr;
+    try {
+        if (qasr::aligner_needs_nl_tokenizer(language ? language : "English")) return -QASR_ERR_UNSUPPORTED;
+        auto pairs = qasr::aligner_split_word_pairs(text);
+        std::vector<std::string> a, b;
+        for (auto& p : pairs) { a.push_back(p.first); b.push_back(p.second); }
+        if (surfaces && !(*surfaces = dup_joined(a))) return -QASR_ERR_INVALID;
+        if (cleaned && !(*cleaned = dup_joined(b))) return -QASR_ERR_INVALID;
+        return (int)pairs.size();
+    } catch (const std::exception&) { return -QASR_ERR_INVALID; }
+}
+
+int qasr_lis_positions(const int32_t* values, size_t n, int32_t* positions) {
+    if ((!values && n) || !positions) return -QASR_ERR_INVALID;
+    try {
+        auto p = qasr::aligner_lis_positions(values, n);
+        std::memcpy(positions, p.data(), p.size() * sizeof(int32_t));
+        return (int)p.size();
+    } catch (const std::exception&) { return -QASR_ERR_INVALID; }
+}
+
+int qasr_enforce_monotonicity(const int32_t* raw, size_t n, int32_t* out) {
+    if ((!raw || !out) && n) return QASR_ERR_INVALID;
+    try {
+        auto v = qasr::aligner_enforce_monotonicity(raw, n);
+        std::memcpy(out, v.data(), v.size() * sizeof(int32_t));
+        return QASR_OK;
+    } catch (const std::exception&) { return QASR_ERR_INVALID; }
+}
+
+int qasr_find_trailing_plateau(const float* start_times, size_t n, float tolerance, int32_t min_size) {
+    if (!start_times && n) return -QASR_ERR_INVALID;
+    return qasr::aligner_find_trailing_plateau(start_times, n, tolerance, min_size);
+}
+
+static int split_for(qasr_engine* e, const char* text, const char* language, std::vector<std::pair<std::string, std::string>>& pairs) {
+    if (qasr::aligner_needs_nl_tokenizer(language ? language : "English"))
+        return fail(e, QASR_ERR_UNSUPPORTED, "the reference splits this language with Apple's NLTokenizer: pass words to qasr_align_words");
+    pairs = qasr::aligner_split_word_pairs(text);
+    return QASR_OK;
+}
+
+int qasr_align_prepare(qasr_engine* e, const char* text, const char* language, int32_t* ids, int32_t ids_cap,
+                       int32_t* ts_positions, int32_t ts_cap, int32_t* n_ts, int32_t* n_words) {
+    if (!e || !text || !ids || !ts_positions) return -1;
+    try {
+        std::vector<std::pair<std::string, std::string>> pairs;
+        if (split_for(e, text, language, pairs)) return -1;
+        auto st = e->impl->prepare_alignment(pairs);
+        if ((int32_t)st.ids.size() > ids_cap || (int32_t)st.ts_pos.size() > ts_cap) { fail(e, QASR_ERR_CAPACITY, "align_prepare: buffer too small"); return -1; }
+        std::memcpy(ids, st.ids.data(), st.ids.size() * sizeof(int32_t));
+        std::memcpy(ts_positions, st.ts_pos.data(), st.ts_pos.size() * sizeof(int32_t));
+        if (n_ts) *n_ts = (int32_t)st.ts_pos.size();
+        if (n_words) *n_words = (int32_t)st.words.size();
+        return (int)st.ids.size();
+    } catch (const std::exception& ex) { fail(e, QASR_ERR_INVALID, ex.what()); return -1; }
+}
+
+int qasr_align_raw(qasr_engine* e, const float* pcm, size_t n, const int32_t* slotted_ids, int32_t n_ids,
+                   const int32_t* ts_positions, int32_t n_ts, int32_t* raw_indices, float* logits) {
+    if (!e || !pcm || !slotted_ids || !ts_positions || !raw_indices || n_ids < 0 || n_ts < 0) return QASR_ERR_INVALID;
+    if (n == 0) return fail(e, QASR_ERR_EMPTY_AUDIO, "empty clip");
+    if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
+    QASR_GUARD(e, {
+        std::vector<std::vector<int32_t>> raw;
+        e->impl->align_forward(&pcm, &n, 1, {std::vector<int32_t>(slotted_ids, slotted_ids + n_ids)},
+                               {std::vector<int32_t>(ts_positions, ts_positions + n_ts)}, raw, logits);
+        if (!raw.empty()) std::memcpy(raw_indices, raw[0].data(), raw[0].size() * sizeof(int32_t));
+    });
+}
+
+static int align_common(qasr_engine* e, const float* pcm, size_t n, int sample_rate,
+                        const std::vector<std::pair<std::string, std::string>>& pairs, bool long_form, qasr_alignment* out) {
+    if (sample_rate != 16000) return fail(e, QASR_ERR_INVALID, "input must be 16 kHz mono (no resampler: AVAudioConverter is not reproducible)");
+    if (n == 0) return fail(e, QASR_ERR_EMPTY_AUDIO, "empty clip");
+    if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
+    QASR_GUARD(e, {
+        const int passes = e->impl->align_words(pcm, n, pairs, long_form);
+        out->words = e->impl->al_view.data();
+        out->n_words = e->impl->al_view.size();
+        out->raw_indices = e->impl->al_raw.data();
+        out->n_indices = e->impl->al_raw.size();
+        out->passes = passes;
+    });
+}
+
+int qasr_align(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* text, const char* language,
+               qasr_alignment* out) {
+    if (!e || !pcm || !text || !out) return QASR_ERR_INVALID;
+    std::vector<std::pair<std::string, std::string>> pairs;
+    try { if (int rc = split_for(e, text, language, pairs)) return rc; }
+    catch (const std::exception& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); }
+    return align_common(e, pcm, n, sample_rate, pairs, false, out);
+}
+
+int qasr_align_long(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* text, const char* language,
+                    qasr_alignment* out) {
+    if (!e || !pcm || !text || !out) return QASR_ERR_INVALID;
+    std::vector<std::pair<std::string, std::string>> pairs;
+    try { if (int rc = split_for(e, text, language, pairs)) return rc; }
+    catch (const std::exception& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); }
+    return align_common(e, pcm, n, sample_rate, pairs, true, out);
+}
+
+int qasr_align_words(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* const* surfaces,
+                     const char* const* cleaned, size_t n_words, qasr_alignment* out) {
+    if (!e || !pcm || !surfaces || !cleaned || !out) return QASR_ERR_INVALID;
+    std::vector<std::pair<std::string, std::string>> pairs;
+    for (size_t i = 0; i < n_words; ++i) {
+        if (!surfaces[i] || !cleaned[i]) return fail(e, QASR_ERR_INVALID, "align_words: null word");
+        pairs.push_back({surfaces[i], cleaned[i]});
+    }
+    return align_common(e, pcm, n, sample_rate, pairs, false, out);
 }
 
 // speech-core bridge (VoicePipeline.swift:374-410): strings stay valid until the next transcribe

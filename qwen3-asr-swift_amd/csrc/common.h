@@ -41,6 +41,12 @@ inline bf16_t f32_to_bf16_host(float f) {
     return (bf16_t)(r >> 16);
 }
 
+inline float bf16_to_f32_host(bf16_t b) {
+    union { uint32_t u; float f; } x;
+    x.u = (uint32_t)b << 16;
+    return x.f;
+}
+
 __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)

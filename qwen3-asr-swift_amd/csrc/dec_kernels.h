@@ -68,6 +68,9 @@ int decode_gemv_launch(DecEpi epi, const DecGemvArgs& a, hipStream_t s);
 int decode_gemv_blocks(DecEpi epi, int N);
 // Decode-step form with the RMSNorm of the input fused into the activation staging (norm_w != null):
 // out = epi( rmsnorm(X) . W^T ).  `norm_scratch` [B][K] is only used by the generic fallback.
+// out[r] = lowest index of the maximum of x[r][0..n) (bf16 logits, MLX argMax tie rule)
+void argmax_rows_launch(const bf16_t* x, long ld, int rows, int n, int* out, hipStream_t s);
+
 // diagnostic: the tuned kernels stamp their phases into dbg[(workgroup*16 + wave)*8 + i] (100 MHz clock); null = off
 void decode_gemv_set_debug(unsigned long long* dbg);
 int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* norm_w, float eps, bf16_t* norm_scratch,

@@ -1361,6 +1361,42 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row argmax over bf16 logits with MLX argMax's tie rule (lowest index): one workgroup per row.  Used by the forced
+// aligner's timestamp head (ForcedAligner.swift:291-296).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restrict__ x, long ld, int n, int* __restrict__ out) {
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    const bf16_t* row = x + (long)blockIdx.x * ld;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = bf16_to_f32(row[i]);
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }     // NaN never wins
+    }
+    s_v[threadIdx.x] = bv;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int ofs = 128; ofs > 0; ofs >>= 1) {
+        if ((int)threadIdx.x < ofs) {
+            const float ov = s_v[threadIdx.x + ofs];
+            const int oi = s_i[threadIdx.x + ofs];
+            if (oi != 0x7fffffff && (s_i[threadIdx.x] == 0x7fffffff || ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x]))) {
+                s_v[threadIdx.x] = ov;
+                s_i[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = s_i[0] == 0x7fffffff ? 0 : s_i[0];
+}
+
+void argmax_rows_launch(const bf16_t* x, long ld, int rows, int n, int* out, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, ld, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // greedy bookkeeping + next-token embedding gather: one workgroup per batch row
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __restrict__ part_val,

@@ -67,7 +67,14 @@ void Engine::finalize_decoder() {
     if (cfg_.inter % 16 != 0 || H % 32 != 0) throw std::invalid_argument("decoder widths must be multiples of 16/32");
     decw_.embed = wptr("model.embed_tokens.weight", {cfg_.vocab, H});
     decw_.norm = wptr("model.norm.weight", {H});
-    decw_.embed_p = packed_copy(decw_.embed, cfg_.vocab, H);
+    // an aligner engine runs the prompt pass only: no decode-step weight images, one K cache shared by all layers
+    const bool aligner = cfg_.classify_num > 0;
+    decw_.embed_p = aligner ? nullptr : packed_copy(decw_.embed, cfg_.vocab, H);
+    if (aligner) {
+        if (cfg_.classify_num % 4 != 0) throw std::invalid_argument("classify_num must be a multiple of 4");
+        decw_.cls_w = wptr("lm_head.weight", {cfg_.classify_num, H});
+        decw_.cls_b = wptr("lm_head.bias", {cfg_.classify_num});
+    }
     decw_.layers.clear();
     for (int i = 0; i < cfg_.dec_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
@@ -95,10 +102,10 @@ void Engine::finalize_decoder() {
         hipLaunchKernelGGL(interleave_gate_up_kernel, dim3(2 * I), dim3(128), 0, stream_, wg, wu, gu->as<bf16_t>(), I, H);
         L.wgu = gu->as<bf16_t>();
         fused_.push_back(std::move(gu));
-        L.wqkv_p = packed_copy(L.wqkv, nq + 2 * nkv, H);
-        L.wo_p = packed_copy(L.wo, H, nq);
-        L.wgu_p = packed_copy(L.wgu, 2 * I, H);
-        L.wdown_p = packed_copy(L.wdown, H, I);
+        L.wqkv_p = aligner ? nullptr : packed_copy(L.wqkv, nq + 2 * nkv, H);
+        L.wo_p = aligner ? nullptr : packed_copy(L.wo, H, nq);
+        L.wgu_p = aligner ? nullptr : packed_copy(L.wgu, 2 * I, H);
+        L.wdown_p = aligner ? nullptr : packed_copy(L.wdown, H, I);
         decw_.layers.push_back(L);
     }
     // capacity: prompt = 16 fixed ids + audio tokens + context/language extras (Qwen3ASR.swift:199-233)
@@ -131,10 +138,11 @@ void Engine::finalize_decoder() {
     vfcache_.clear();
     const size_t cache_bytes = (size_t)B * cfg_.kv_heads * max_ctx_ * hd * sizeof(bf16_t);
     d_vrows_.alloc(cache_bytes);          // row-major V of the layer in flight (prompt pass only)
-    for (int i = 0; i < cfg_.dec_layers; ++i) {
+    for (int i = 0; i < (aligner ? 1 : cfg_.dec_layers); ++i) {
         kcache_.push_back(std::make_unique<DevBuf>());
-        vfcache_.push_back(std::make_unique<DevBuf>());
         kcache_.back()->alloc(cache_bytes);
+        if (aligner) break;
+        vfcache_.push_back(std::make_unique<DevBuf>());
         vfcache_.back()->alloc(cache_bytes);
     }
     d_rope_rows_.alloc((size_t)2 * B * (hd / 2) * sizeof(float));
@@ -185,11 +193,17 @@ void Engine::finalize_decoder() {
 }
 
 // ---- prompt planning (integer work, R7) ----------------------------------------------------------
-void Engine::plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio) {
+void Engine::plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio,
+                          const std::vector<std::vector<int32_t>>* aligner_tails) {
     const int B = (int)n_audio.size();
     const int n_ctx = opt && opt->context_ids ? opt->n_context : 0;
     const int n_lang = opt && opt->language_ids ? opt->n_language : 0;
     if (n_ctx + n_lang > cfg_.max_prompt_extra) throw std::length_error("context + language ids exceed max_prompt_extra");
+    if (aligner_tails) {
+        if ((int)aligner_tails->size() != B) throw std::invalid_argument("aligner: one slotted text per clip");
+        for (auto& t : *aligner_tails)
+            if ((int)t.size() > cfg_.max_prompt_extra) throw std::length_error("slotted text exceeds max_prompt_extra");
+    }
     char* hp = h_pmeta_.as<char>();
     int* ids = reinterpret_cast<int*>(hp);
     int* asrc = ids + max_pos_;
@@ -213,8 +227,13 @@ void Engine::plan_prefill(const qasr_options* opt, const std::vector<int>& n_aud
         for (int i = 0; i < n_audio[b]; ++i) push(cfg_.tok_audio_pad, clip_tok_off_[b] + i);
         push(cfg_.tok_audio_end, -1); push(cfg_.tok_im_end, -1); push(cfg_.tok_newline, -1);
         push(cfg_.tok_im_start, -1); push(cfg_.tok_assistant, -1); push(cfg_.tok_newline, -1);
-        for (int i = 0; i < n_lang; ++i) push(opt->language_ids[i], -1);
-        push(cfg_.tok_asr_text, -1);
+        if (aligner_tails) {
+            // ForcedAligner.swift:337-378: the same template, then the text with <timestamp> slots; no <asr_text>
+            for (int32_t id : (*aligner_tails)[b]) push(id, -1);
+        } else {
+            for (int i = 0; i < n_lang; ++i) push(opt->language_ids[i], -1);
+            push(cfg_.tok_asr_text, -1);
+        }
         prompt_len_[b] = p - start;
         if (prompt_len_[b] > max_prompt_) throw std::length_error("prompt longer than engine capacity");
         max_len_ = std::max(max_len_, prompt_len_[b]);
@@ -272,7 +291,9 @@ void Engine::run_prefill(bool want_logits) {
     embed_splice_launch(d_p_ids_, d_p_audio_src_, decw_.embed, d_audio_.as<bf16_t>(), x, P, H, s);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
-        KVLayout kv{kcache_[l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
+        const bool aligner = cfg_.classify_num > 0;
+        KVLayout kv{kcache_[aligner ? 0 : l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd,
+                    aligner ? nullptr : vfcache_[l]->as<bf16_t>()};
         rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
         gemm_nt(ADense{h, H, P, H}, L.wqkv, H, P, nh * hd, H, EpiBiasActBf16<0>{qkv, (long)nh * hd, nullptr}, s);
         qk_norm_rope_launch(qkv, d_p_slot_, d_p_pos_, P, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
@@ -285,10 +306,79 @@ void Engine::run_prefill(bool want_logits) {
         gemm_nt_swiglu(ADense{h, H, P, H}, L.wgu, H, P, 2 * I, H, EpiBiasActBf16<0>{act, I, nullptr}, s);
         gemm_nt(ADense{act, I, P, I}, L.wdown, I, P, H, I, EpiResidBf16{x, H}, s);
     }
+    if (cfg_.classify_num > 0) { QASR_HIP(hipGetLastError()); return; }      // aligner: the caller reads d_px_ rows
     // last position of every clip -> decode rows (Qwen3ASR.swift:254-256)
     gather_rows_launch(x, d_p_last_, d_dx_.as<bf16_t>(), batch_, H, s);
     run_lm_head(want_logits, 0, batch_, s);
     QASR_HIP(hipGetLastError());
+}
+
+// Forced aligner forward (ForcedAligner.swift:236-299) for a batch of clips: mel -> encoder -> one decoder pass over
+// [template + audio + slotted text] -> final RMSNorm + Linear(hidden, classify_num) at the timestamp slots -> argmax.
+// raw[b] receives one class index per slot of clip b; logits (optional) [sum n_ts, classify_num] f32.
+void Engine::align_forward(const float* const* pcm, const size_t* n, size_t B,
+                           const std::vector<std::vector<int32_t>>& slotted,
+                           const std::vector<std::vector<int32_t>>& ts_pos, std::vector<std::vector<int32_t>>& raw,
+                           float* logits) {
+    if (!finalized_) throw std::runtime_error("weights not finalized");
+    if (cfg_.classify_num <= 0) throw std::runtime_error("this engine has no timestamp head (create it from an aligner preset)");
+    if (B == 0 || slotted.size() != B || ts_pos.size() != B) throw std::invalid_argument("align: one slotted text per clip");
+    const int H = cfg_.hidden, C = cfg_.classify_num;
+    upload_pcm(pcm, n, B);
+    plan_encoder();
+    std::vector<int> n_audio;
+    for (auto& c : clips_) n_audio.push_back(c.n_tokens);
+    plan_prefill(nullptr, n_audio, &slotted);
+    // packed row of slot j of clip b: cu[b] + 9 template ids + audio + 6 template ids + position inside the text
+    std::vector<int> rows;
+    int p0 = 0;
+    for (size_t b = 0; b < B; ++b) {
+        const int text0 = p0 + 9 + n_audio[b] + 6;
+        for (int32_t q : ts_pos[b]) {
+            if (q < 0 || q >= (int)slotted[b].size()) throw std::invalid_argument("align: timestamp position outside the text");
+            rows.push_back(text0 + q);
+        }
+        p0 += prompt_len_[b];
+    }
+    const int R = (int)rows.size();
+    if (R == 0) { raw.assign(B, {}); return; }
+    if (R > max_pos_) throw std::length_error("align: more timestamp slots than prompt positions");
+    hipStream_t s = stream_;
+    if (d_al_rows_.bytes < (size_t)R * sizeof(int)) d_al_rows_.alloc((size_t)R * sizeof(int));
+    if (d_al_x_.bytes < (size_t)R * H * 2 * 2) d_al_x_.alloc((size_t)R * H * 2 * 2);
+    if (d_al_logits_.bytes < (size_t)R * C * 2) d_al_logits_.alloc((size_t)R * C * 2);
+    if (d_al_idx_.bytes < (size_t)R * sizeof(int)) d_al_idx_.alloc((size_t)R * sizeof(int));
+    QASR_HIP(hipMemcpyAsync(d_al_rows_.p, rows.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice, s));
+    QASR_HIP(hipEventRecord(ev_[0], s));
+    run_mel();
+    QASR_HIP(hipEventRecord(ev_[1], s));
+    run_encoder();
+    QASR_HIP(hipEventRecord(ev_[2], s));
+    run_prefill(false);
+    bf16_t* xr = d_al_x_.as<bf16_t>();
+    bf16_t* xn = xr + (size_t)R * H;
+    gather_rows_launch(d_px_.as<bf16_t>(), d_al_rows_.as<int>(), xr, R, H, s);
+    rmsnorm_rows_launch(xr, decw_.norm, xn, R, H, cfg_.rms_eps, s);
+    // MLX Linear = addmm(bias, x, W^T): one rounding of acc + bias to the decoder dtype (ForcedAligner.swift:283)
+    gemm_nt(ADense{xn, H, R, H}, decw_.cls_w, H, R, C, H, EpiBiasActBf16<0>{d_al_logits_.as<bf16_t>(), (long)C, decw_.cls_b}, s);
+    argmax_rows_launch(d_al_logits_.as<bf16_t>(), C, R, C, d_al_idx_.as<int>(), s);
+    QASR_HIP(hipEventRecord(ev_[3], s));
+    QASR_HIP(hipEventRecord(ev_[4], s));
+    std::vector<int> idx(R);
+    QASR_HIP(hipMemcpyAsync(idx.data(), d_al_idx_.p, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, s));
+    std::vector<bf16_t> lg;
+    if (logits) {
+        lg.resize((size_t)R * C);
+        QASR_HIP(hipMemcpyAsync(lg.data(), d_al_logits_.p, lg.size() * 2, hipMemcpyDeviceToHost, s));
+    }
+    QASR_HIP(hipStreamSynchronize(s));
+    QASR_HIP(hipGetLastError());
+    if (logits)
+        for (size_t i = 0; i < lg.size(); ++i) logits[i] = bf16_to_f32_host(lg[i]);
+    raw.assign(B, {});
+    int k = 0;
+    for (size_t b = 0; b < B; ++b)
+        for (size_t j = 0; j < ts_pos[b].size(); ++j) raw[b].push_back(idx[k++]);
 }
 
 RopeRows Engine::rope_rows(int r0) const {
@@ -492,6 +582,7 @@ void Engine::decode_loop_slow() {
 // ---- batch pipeline --------------------------------------------------------------------------------
 void Engine::batch_begin(const float* const* pcm, const size_t* n, size_t B, const qasr_options* opt) {
     if (!finalized_) throw std::runtime_error("weights not finalized");
+    require_asr("transcribe");
     if (B == 0) throw std::invalid_argument("empty batch");
     int max_tokens = opt && opt->max_tokens > 0 ? opt->max_tokens : cfg_.max_new_tokens;
     if (max_tokens > cfg_.max_new_tokens) throw std::length_error("max_tokens exceeds engine capacity");
@@ -556,6 +647,7 @@ void Engine::batch_timings(float ms[5], int32_t* n_steps) {
 //   2: LM head (vocab x hidden bf16)
 void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_launch) {
     if (!finalized_ || batch_ <= 0) throw std::runtime_error("kernel_probe needs a prepared batch");
+    require_asr("kernel_probe");
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
     const DecLayerW& L = decw_.layers[0];
     KVLayout kv{kcache_[0]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[0]->as<bf16_t>()};
@@ -691,6 +783,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
 // ---- stage entry points ------------------------------------------------------------------------------
 void Engine::prefill_logits_host(const float* audio_embeds, int n_audio, const qasr_options* opt, float* logits) {
     if (!finalized_) throw std::runtime_error("weights not finalized");
+    require_asr("prefill_logits");
     if (n_audio < 0 || n_audio > max_tokens_) throw std::length_error("prefill: too many audio tokens");
     batch_ = 1;
     clips_.assign(1, ClipPlan{});
@@ -712,6 +805,7 @@ void Engine::prefill_logits_host(const float* audio_embeds, int n_audio, const q
 
 void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
     if (!finalized_ || batch_ != 1) throw std::runtime_error("decode_forced needs a preceding prefill_logits");
+    require_asr("decode_forced");
     HostBuf idx;
     idx.alloc(sizeof(int));
     DevBuf didx;

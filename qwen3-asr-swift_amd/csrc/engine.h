@@ -102,6 +102,20 @@ public:
     void batch_timings(float ms[5], int32_t* n_steps);
     void kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_launch);
     int batch_size() const { return batch_; }
+    void require_asr(const char* what) const {
+        if (cfg_.classify_num > 0) throw std::runtime_error(std::string(what) + ": this engine is a forced aligner (no LM head / decode state)");
+    }
+
+    // forced aligner (N3): device forward + the host logic of csrc/aligner.cpp
+    void align_forward(const float* const* pcm, const size_t* n, size_t B, const std::vector<std::vector<int32_t>>& slotted,
+                       const std::vector<std::vector<int32_t>>& ts_pos, std::vector<std::vector<int32_t>>& raw, float* logits);
+    struct AlignedWord { std::string text; float start, end; };
+    struct SlottedText { std::vector<int32_t> ids, ts_pos; std::vector<std::string> words; };
+    SlottedText prepare_alignment(const std::vector<std::pair<std::string, std::string>>& pairs) const;
+    int align_words(const float* pcm, size_t n, const std::vector<std::pair<std::string, std::string>>& pairs, bool long_form);
+    std::vector<AlignedWord> al_words;         // owned result storage for qasr_align*
+    std::vector<qasr_aligned_word> al_view;
+    std::vector<int32_t> al_raw;
 
     // tokenizer (R9)
     void set_vocab(const int32_t* ids, const char* const* tokens, size_t n);
@@ -125,7 +139,8 @@ private:
     void run_encoder();
     void finalize_decoder();
     const bf16_t* packed_copy(const bf16_t* w, int N, int K);
-    void plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio);
+    void plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio,
+                      const std::vector<std::vector<int32_t>>* aligner_tails = nullptr);
     void run_prefill(bool want_logits);
     void run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s, bool with_head);
     void issue_decode_step(int split);
@@ -185,11 +200,13 @@ private:
     };
     struct DecW {
         const bf16_t *embed, *norm, *embed_p;
+        const bf16_t *cls_w = nullptr, *cls_b = nullptr;       // aligner: Linear(hidden, classify_num) `lm_head.{weight,bias}`
         std::vector<DecLayerW> layers;
     } decw_;
     int max_prompt_ = 0, max_ctx_ = 0, max_pos_ = 0, vt_stride_ = 0;
     DevBuf d_rope_cos_, d_rope_sin_, d_rope_rows_;    // tables [max_ctx][hd/2]; per-row copies for the next step
     std::vector<std::unique_ptr<DevBuf>> kcache_, vfcache_;     // per layer: keys row-major, values fragment-major
+    DevBuf d_al_rows_, d_al_x_, d_al_logits_, d_al_idx_;         // aligner head workspace (grown on demand)
     DevBuf d_vrows_;                                            // row-major V of one layer (prompt-pass scratch)
     DevBuf d_vt_;
     DevBuf d_px_, d_ph_, d_pqkv_, d_pqr_, d_pattn_, d_pact_;   // prefill (packed prompt positions)
@@ -228,5 +245,12 @@ private:
     uint64_t opt_seed_ = 0;
     void decode_loop_slow();
 };
+
+// host logic of the forced aligner (aligner.cpp)
+bool aligner_needs_nl_tokenizer(const std::string& language);
+std::vector<std::pair<std::string, std::string>> aligner_split_word_pairs(const std::string& text);     // (surface, cleaned)
+std::vector<int32_t> aligner_lis_positions(const int32_t* values, size_t n);
+std::vector<int32_t> aligner_enforce_monotonicity(const int32_t* raw, size_t n);
+int aligner_find_trailing_plateau(const float* start_times, size_t n, float tolerance, int min_size);
 
 }  // namespace qasr

@@ -119,10 +119,37 @@ void Engine::load_directory(const std::string& dir) {
         for (size_t i = 0; i < numel; ++i) tmp[i] = f32_to_bf16_host(elem_f32(e, i));
         set_tensor(name, tmp.data(), QASR_DTYPE_BF16, e.shape.data(), (int)e.shape.size());
     };
+    // Forced-aligner checkpoints (WeightLoader.loadForcedAlignerWeights, WeightLoading.swift:135-232) prefix every key
+    // with "thinker.", keep the Conv2d weights in PyTorch layout [out, in, kH, kW] (transposed to the engine's
+    // [out, kH, kW, in] here, :184-187) and carry the un-quantised classify head as `lm_head.{weight,bias}`.
+    const bool aligner = cfg_.classify_num > 0;
+    if (aligner) {
+        std::map<std::string, Entry> stripped;
+        for (auto& kv : entries)
+            stripped[kv.first.compare(0, 8, "thinker.") == 0 ? kv.first.substr(8) : kv.first] = kv.second;
+        entries.swap(stripped);
+    }
     for (auto& kv : entries) {
         const std::string& name = kv.first;
         const bool audio = name.compare(0, 12, "audio_tower.") == 0, text = name.compare(0, 6, "model.") == 0;
-        if (!audio && !text) continue;
+        const bool head = aligner && name.compare(0, 8, "lm_head.") == 0;
+        if (!audio && !text && !head) continue;
+        if (aligner && audio && name.find(".conv2d") != std::string::npos && name.size() > 7 &&
+            name.compare(name.size() - 7, 7, ".weight") == 0) {
+            const Entry& e = kv.second;
+            if (e.shape.size() != 4 || e.shape[2] != 3 || e.shape[3] != 3) throw std::runtime_error(name + ": expected a PyTorch [out, in, 3, 3] conv weight");
+            const int64_t O = e.shape[0], I = e.shape[1];
+            const size_t el = e.dtype == "F32" ? 4 : 2;
+            if ((size_t)(O * I * 9) * el != e.bytes) throw std::runtime_error("tensor " + name + ": byte size does not match shape");
+            tmp.resize((size_t)(O * I * 9));
+            for (int64_t o = 0; o < O; ++o)
+                for (int64_t i = 0; i < I; ++i)
+                    for (int64_t k = 0; k < 9; ++k)
+                        tmp[(size_t)((o * 9 + k) * I + i)] = f32_to_bf16_host(elem_f32(e, (size_t)((o * I + i) * 9 + k)));
+            int64_t shp[4] = {O, 3, 3, I};
+            set_tensor(name, tmp.data(), QASR_DTYPE_BF16, shp, 4);
+            continue;
+        }
         auto ends = [&](const char* s) { size_t l = strlen(s); return name.size() > l && name.compare(name.size() - l, l, s) == 0; };
         if (ends(".scales") || ends(".biases")) continue;            // consumed with their .weight
         const Entry& e = kv.second;

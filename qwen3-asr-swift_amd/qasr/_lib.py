@@ -17,7 +17,8 @@ class QasrConfig(C.Structure):
                                          "tok_user", "tok_assistant")] + \
                [("fft_scale", C.c_float)] + \
                [(n, C.c_int32) for n in ("device", "max_batch", "max_audio_seconds", "max_new_tokens",
-                                         "max_prompt_extra")]
+                                         "max_prompt_extra", "classify_num", "tok_timestamp")] + \
+               [("timestamp_segment_time", C.c_float)]
 
 
 class QasrOptions(C.Structure):
@@ -35,6 +36,15 @@ class QasrResult(C.Structure):
 class ScTranscriptionResult(C.Structure):
     _fields_ = [("text", C.c_char_p), ("language", C.c_char_p), ("confidence", C.c_float),
                 ("start_time", C.c_float), ("end_time", C.c_float)]
+
+
+class QasrAlignedWord(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("start_time", C.c_float), ("end_time", C.c_float)]
+
+
+class QasrAlignment(C.Structure):
+    _fields_ = [("words", C.POINTER(QasrAlignedWord)), ("n_words", C.c_size_t),
+                ("raw_indices", C.POINTER(C.c_int32)), ("n_indices", C.c_size_t), ("passes", C.c_int32)]
 
 
 SC_TRANSCRIBE_FN = C.CFUNCTYPE(ScTranscriptionResult, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int)
@@ -87,6 +97,15 @@ SIGNATURES = {
     "qasr_encode": (C.c_int, [_E, _F, C.c_int, _F]),
     "qasr_prefill_logits": (C.c_int, [_E, _F, C.c_int, _P(QasrOptions), _F]),
     "qasr_decode_forced": (C.c_int, [_E, _I, C.c_int, _F]),
+    "qasr_split_words": (C.c_int, [C.c_char_p, C.c_char_p, _P(C.c_void_p), _P(C.c_void_p)]),
+    "qasr_lis_positions": (C.c_int, [_I, C.c_size_t, _I]),
+    "qasr_enforce_monotonicity": (C.c_int, [_I, C.c_size_t, _I]),
+    "qasr_find_trailing_plateau": (C.c_int, [_F, C.c_size_t, C.c_float, C.c_int32]),
+    "qasr_align_prepare": (C.c_int, [_E, C.c_char_p, C.c_char_p, _I, C.c_int32, _I, C.c_int32, _I, _I]),
+    "qasr_align_raw": (C.c_int, [_E, _F, C.c_size_t, _I, C.c_int32, _I, C.c_int32, _I, _F]),
+    "qasr_align": (C.c_int, [_E, _F, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p, _P(QasrAlignment)]),
+    "qasr_align_words": (C.c_int, [_E, _F, C.c_size_t, C.c_int, _P(C.c_char_p), _P(C.c_char_p), C.c_size_t, _P(QasrAlignment)]),
+    "qasr_align_long": (C.c_int, [_E, _F, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p, _P(QasrAlignment)]),
 }
 
 _lib = None

@@ -26,8 +26,9 @@ def synth_waveform(k: int, seconds: float, sample_rate: int = 16000) -> np.ndarr
     return (pcm16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
 
 
-def synth_state_dict(audio_cfg, text_cfg, seed: int = 0, init: str = "hf", dtype=torch.bfloat16):
-    """audio_cfg / text_cfg: any objects with the fields of qasr.config presets."""
+def synth_state_dict(audio_cfg, text_cfg, seed: int = 0, init: str = "hf", dtype=torch.bfloat16, classify_num: int = 0):
+    """audio_cfg / text_cfg: any objects with the fields of qasr.config presets.  classify_num > 0 adds the forced
+    aligner's `lm_head.{weight,bias}` Linear(hidden, classify_num) (WeightLoading.swift:228-230)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -85,4 +86,8 @@ def synth_state_dict(audio_cfg, text_cfg, seed: int = 0, init: str = "hf", dtype
         w(f"{p}.mlp.up_proj.weight", t.inter, t.hidden)
         w(f"{p}.mlp.down_proj.weight", t.hidden, t.inter)
     gain("model.norm.weight", t.hidden)
+    if classify_num:
+        std = 0.02 if init == "hf" else 1.0 / math.sqrt(t.hidden)
+        sd["lm_head.weight"] = (torch.randn(classify_num, t.hidden, generator=g) * std).to(dtype)
+        sd["lm_head.bias"] = (torch.randn(classify_num, generator=g) * 0.05).to(dtype)
     return sd
