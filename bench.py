@@ -151,15 +151,17 @@ def main():
     if rank == 0:
         audio_s = world * B * args.seconds * args.steps
         ms_step = dt / args.steps * 1e3
-        # dominant kernel by GPU time (profiles/r01_v5_bench_kernel_stats.csv: 32 %): decode_attention_kernel
+        # dominant kernel by GPU time (profiles/*_bench_kernel_stats.csv): decode_attention_mfma_kernel
         dom_ms, dom_bytes = probe["decode_attn"]
         traffic, traffic_note = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")
-        if os.path.exists(pmc_path):       # measured in separate rocprofv3 --pmc passes (see the file's "source")
-            pmc = json.load(open(pmc_path))
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if pmc_files:                      # measured in separate rocprofv3 --pmc passes (see the file's "source")
+            pmc = json.load(open(pmc_files[-1]))
             traffic = pmc.get("decode_attention_bytes")
-            traffic_note = ("profiles/r01_v5_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc "
-                            "passes at mean context 414 where the algorithmic bytes are 54.3e6 (ratio 1.015)")
+            alg = pmc.get("decode_attention_algorithmic_bytes_at_that_context")
+            traffic_note = (f"profiles/{os.path.basename(pmc_files[-1])}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate "
+                            f"--pmc passes of a 16-token run; algorithmic bytes at that run's mean context: {alg}")
         out = {
             "metric": "audio-seconds/sec (RTF^-1) Qwen3-ASR-0.6B, 30 s@16 kHz, b=32 per GPU",
             "value": round(audio_s / dt, 1),
@@ -179,7 +181,7 @@ def main():
                          "decode_steps": steps_done},
             "pcie_inclusive_value": round(world * B * args.seconds / (ms_step / 1e3 + h2d_s), 1),
             "roofline": {"bound": "hbm",
-                         "kernel": "decode_attention_kernel (one launch = one decoder layer's attention for all batch rows: "
+                         "kernel": "decode_attention_mfma_kernel (one launch = one decoder layer's attention for all batch rows: "
                                    "K and V rows of every row's context are streamed once)",
                          "achieved": round(dom_bytes / dom_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,

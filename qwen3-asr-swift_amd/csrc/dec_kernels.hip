@@ -1138,10 +1138,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     const bf16_t* vfb = cache.vf + cache.off(b, kvh, 0) + lane * 8;
     const int max_chunk = cache.max_ctx / 32 - 1;
     uint4 kreg[UNR][2 * KS], vreg[UNR][DT];
-    auto issue = [&](int chunk0) {
+    auto issue = [&](int chunk0, int limit) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             int ch = chunk0 + u * WAVES;
+            if (ch >= limit) continue;                                   // wave-uniform: no bytes for chunks past the context
             ch = ch < max_chunk ? ch : max_chunk;                        // clamped to the allocation, masked later
             const bf16_t* kr = kb + ((long)ch * 32 + fr) * HD;
 #pragma unroll
@@ -1156,11 +1157,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     };
     int pos;
     if (SPEC) {
-        issue(wave);                         // before the position is known: rows past it are masked
+        issue(wave, 0x7fffffff);             // before the position is known: rows past it are masked
         pos = ctx_len[b];
     } else {
         pos = ctx_len[b];
-        if (wave * 32 < pos) issue(wave);
+        issue(wave, (pos + 31) >> 5);
     }
     const int nchunks = (pos + 31) >> 5;
     const int nh = heads + 2 * kv_heads;
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.0f;
     for (int c0 = wave; c0 < nchunks; c0 += WAVES * UNR) {
-        if (c0 != wave) issue(c0);
+        if (c0 != wave) issue(c0, nchunks);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int chunk = c0 + u * WAVES;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of several builds inside one box (scratch/lib_alt/<name>/libqasr.so), two rounds (drift check)
-export QASR_DA_WAVES=8 QASR_DA_MFMA=2
+# defaults
 cp qwen3-asr-swift_amd/lib/libqasr.so /tmp/main.so
 for round in 1 2; do
 for v in $(ls scratch/lib_alt); do
