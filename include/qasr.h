@@ -246,6 +246,10 @@ int qasr_align(qasr_engine* e, const float* pcm, size_t n, int sample_rate, cons
 /* the same with caller-split words (surface + cleaned form per word): the NLTokenizer languages. */
 int qasr_align_words(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* const* surfaces,
                      const char* const* cleaned, size_t n_words, qasr_alignment* out);
+/* Batched single-pass align (new: the reference aligns one utterance at a time): B clips with one text each, one
+ * mel / encoder / decoder pass over the packed batch; out[b] as for qasr_align (all owned by the engine). */
+int qasr_align_batch(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
+                     const char* const* texts, const char* language, qasr_alignment* out);
 /* alignLong: re-aligns the remainder while a trailing plateau (>= 5 words within 0.1 s) is detected on audio longer
  * than 240 s, at most 10 passes (ForcedAligner.swift:97-180). */
 int qasr_align_long(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* text,

@@ -292,4 +292,30 @@ int Engine::align_words(const float* pcm, size_t n, const std::vector<std::pair<
     return pass;
 }
 
+// one pass over B clips (ForcedAligner.swift:226-331 per clip); clips whose text has no encodable word get no words
+void Engine::align_batch(const float* const* pcm, const size_t* n, size_t B,
+                         const std::vector<std::vector<std::pair<std::string, std::string>>>& pairs) {
+    if (pairs.size() != B) throw std::invalid_argument("align_batch: one text per clip");
+    std::vector<SlottedText> st(B);
+    std::vector<std::vector<int32_t>> ids(B), ts(B), raw;
+    for (size_t b = 0; b < B; ++b) {
+        st[b] = prepare_alignment(pairs[b]);
+        ids[b] = st[b].ids;
+        ts[b] = st[b].ts_pos;
+    }
+    align_forward(pcm, n, B, ids, ts, raw, nullptr);
+    al_batch.assign(B, AlignResult{});
+    const float seg_t = cfg_.timestamp_segment_time;
+    for (size_t b = 0; b < B; ++b) {
+        AlignResult& r = al_batch[b];
+        if (b < raw.size()) r.raw = raw[b];
+        const std::vector<int32_t> fixed = aligner_enforce_monotonicity(r.raw.data(), r.raw.size());
+        for (size_t w = 0; w < st[b].words.size() && 2 * w + 1 < fixed.size(); ++w) {
+            const float s = (float)fixed[2 * w] * seg_t, e = (float)fixed[2 * w + 1] * seg_t;
+            r.words.push_back({st[b].words[w], s, std::max(e, s)});
+        }
+        for (auto& w : r.words) r.view.push_back({w.text.c_str(), w.start, w.end});
+    }
+}
+
 }  // namespace qasr

@@ -326,6 +326,31 @@ int qasr_align_long(qasr_engine* e, const float* pcm, size_t n, int sample_rate,
     return align_common(e, pcm, n, sample_rate, pairs, true, out);
 }
 
+int qasr_align_batch(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
+                     const char* const* texts, const char* language, qasr_alignment* out) {
+    if (!e || !pcm || !n || !texts || !out || B == 0) return QASR_ERR_INVALID;
+    if (sample_rate != 16000) return fail(e, QASR_ERR_INVALID, "input must be 16 kHz mono (no resampler: AVAudioConverter is not reproducible)");
+    if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
+    std::vector<std::vector<std::pair<std::string, std::string>>> pairs(B);
+    for (size_t b = 0; b < B; ++b) {
+        if (!pcm[b] || !texts[b]) return fail(e, QASR_ERR_INVALID, "align_batch: null clip or text");
+        if (n[b] == 0) return fail(e, QASR_ERR_EMPTY_AUDIO, "empty clip");
+        try { if (int rc = split_for(e, texts[b], language, pairs[b])) return rc; }
+        catch (const std::exception& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); }
+    }
+    QASR_GUARD(e, {
+        e->impl->align_batch(pcm, n, B, pairs);
+        for (size_t b = 0; b < B; ++b) {
+            auto& r = e->impl->al_batch[b];
+            out[b].words = r.view.data();
+            out[b].n_words = r.view.size();
+            out[b].raw_indices = r.raw.data();
+            out[b].n_indices = r.raw.size();
+            out[b].passes = 1;
+        }
+    });
+}
+
 int qasr_align_words(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* const* surfaces,
                      const char* const* cleaned, size_t n_words, qasr_alignment* out) {
     if (!e || !pcm || !surfaces || !cleaned || !out) return QASR_ERR_INVALID;

@@ -113,6 +113,10 @@ public:
     struct SlottedText { std::vector<int32_t> ids, ts_pos; std::vector<std::string> words; };
     SlottedText prepare_alignment(const std::vector<std::pair<std::string, std::string>>& pairs) const;
     int align_words(const float* pcm, size_t n, const std::vector<std::pair<std::string, std::string>>& pairs, bool long_form);
+    void align_batch(const float* const* pcm, const size_t* n, size_t B,
+                     const std::vector<std::vector<std::pair<std::string, std::string>>>& pairs);
+    struct AlignResult { std::vector<AlignedWord> words; std::vector<qasr_aligned_word> view; std::vector<int32_t> raw; };
+    std::vector<AlignResult> al_batch;         // owned result storage for qasr_align_batch
     std::vector<AlignedWord> al_words;         // owned result storage for qasr_align*
     std::vector<qasr_aligned_word> al_view;
     std::vector<int32_t> al_raw;

@@ -105,6 +105,7 @@ SIGNATURES = {
     "qasr_align_raw": (C.c_int, [_E, _F, C.c_size_t, _I, C.c_int32, _I, C.c_int32, _I, _F]),
     "qasr_align": (C.c_int, [_E, _F, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p, _P(QasrAlignment)]),
     "qasr_align_words": (C.c_int, [_E, _F, C.c_size_t, C.c_int, _P(C.c_char_p), _P(C.c_char_p), C.c_size_t, _P(QasrAlignment)]),
+    "qasr_align_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(C.c_char_p), C.c_char_p, _P(QasrAlignment)]),
     "qasr_align_long": (C.c_int, [_E, _F, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p, _P(QasrAlignment)]),
 }
 

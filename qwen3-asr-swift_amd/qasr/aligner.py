@@ -134,6 +134,23 @@ class Qwen3ForcedAligner(Qwen3ASRModel):
                                             language.encode("utf-8"), C.byref(out)))
         return self._result(out)
 
+    def align_batch(self, clips, texts, sample_rate=16000, language="English"):
+        """New batched surface: B clips + B texts in one device pass -> [[AlignedWord]] (single-pass align per clip)."""
+        arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        B = len(arrs)
+        ptrs = (C.POINTER(C.c_float) * B)(*[_fptr(a) for a in arrs])
+        ns = (C.c_size_t * B)(*[a.shape[0] for a in arrs])
+        txt = (C.c_char_p * B)(*[t.encode("utf-8") for t in texts])
+        out = (_lib.QasrAlignment * B)()
+        self._check(self.lib.qasr_align_batch(self.h, ptrs, ns, B, sample_rate, txt, language.encode("utf-8"), out))
+        res = []
+        self.last_raw_batch = []
+        for b in range(B):
+            o = out[b]
+            res.append([AlignedWord(o.words[i].text.decode("utf-8"), o.words[i].start_time, o.words[i].end_time) for i in range(o.n_words)])
+            self.last_raw_batch.append([o.raw_indices[i] for i in range(o.n_indices)])
+        return res
+
     def align_long(self, audio, text, sample_rate=16000, language="English"):
         pcm = np.ascontiguousarray(audio, dtype=np.float32)
         out = _lib.QasrAlignment()

@@ -135,6 +135,25 @@ def test_align_long_driver_matches_oracle(seed, tseed, exp_passes):
         m.close()
 
 
+def test_align_batch_equals_single_clip_calls(tiny):
+    """Ragged batch (different lengths, different texts, one text without any word) in one device pass == B single calls,
+    bit for bit (clips are independent: per-clip mel max, windows, causal prompt)."""
+    m, _, _, _ = tiny
+    clips = [synth.synth_waveform(k, sec) for k, sec in enumerate((2.0, 6.5, 0.7, 4.0))]
+    texts = ["a language", "English lists, a lan gua! fin", "...", "lists"]
+    single = [m.align(c, t) for c, t in zip(clips, texts)]
+    raws = []
+    for c, t in zip(clips, texts):
+        m.align(c, t)
+        raws.append(m.last_raw_indices if t != "..." else [])
+    got = m.align_batch(clips, texts)
+    assert got == single and got[2] == []
+    assert m.last_raw_batch == raws
+    assert m.align_batch(clips[::-1], texts[::-1]) == single[::-1]          # batch order / composition invariance
+    with pytest.raises(Exception):
+        m.align_batch(clips * 3, texts * 3)                                # 12 clips > max_batch 8
+
+
 def test_errors(tiny):
     m, _, _, _ = tiny
     pcm = synth.synth_waveform(0, 1.0)
