@@ -71,6 +71,32 @@ def cpu_baseline(sd, pcm, n_dec):
                       f"{dt:.1f} s of CPU work"}
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
+
+
+def stage_roofline(B, seconds, n_dec, stage_ms, steps):
+    """Per-stage achieved rate of the last timed pass against the bound SURVEY.md section 8(d) names for it, from the
+    survey's algorithmic work per 30 s clip (scaled linearly with the clip length) and the HIP-event stage times."""
+    k = seconds / 30.0
+    audio_tok = 13.0 * seconds                       # 390 audio tokens per 30 s
+    prompt = 16 + audio_tok
+    mel_b = 3.456e6 * k * B
+    enc_f = 270.7e9 * k * B
+    pre_f = 376.8e9 * k * B                          # (mildly superlinear in T through attention; 30 s is the quoted case)
+    # decode: weights once per step for the whole batch + every row's K/V rows; the first token comes from the prompt pass
+    dec_b = steps * 1.192e9 + B * 114688.0 * sum(prompt + i for i in range(steps))
+    out = {"mel": {"bound": "hbm", "achieved": round(mel_b / stage_ms[0] / 1e6, 1), "unit": "GB/s", "frac": round(mel_b / stage_ms[0] / 1e6 / HBM_PEAK_GBS, 4)},
+           "encoder": {"bound": "mfma", "achieved": round(enc_f / stage_ms[1] / 1e9, 1), "unit": "TFLOP/s",
+                       "frac": round(enc_f / stage_ms[1] / 1e9 / MFMA_PEAK_TFLOPS, 4)},
+           "prompt_pass": {"bound": "mfma", "achieved": round(pre_f / stage_ms[2] / 1e9, 1), "unit": "TFLOP/s",
+                           "frac": round(pre_f / stage_ms[2] / 1e9 / MFMA_PEAK_TFLOPS, 4)}}
+    if steps > 0 and stage_ms[3] > 0:
+        out["decode"] = {"bound": "hbm", "achieved": round(dec_b / stage_ms[3] / 1e6, 1), "unit": "GB/s",
+                         "frac": round(dec_b / stage_ms[3] / 1e6 / HBM_PEAK_GBS, 4),
+                         "bytes_per_step": round(dec_b / steps)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +206,7 @@ def main():
                          "prompt_pass": round(stage_ms[2], 3), "decode": round(stage_ms[3], 3),
                          "decode_steps": steps_done},
             "pcie_inclusive_value": round(world * B * args.seconds / (ms_step / 1e3 + h2d_s), 1),
+            "stage_roofline": stage_roofline(B, args.seconds, n_dec, stage_ms, steps_done),
             "roofline": {"bound": "hbm",
                          "kernel": "decode_attention_mfma_kernel (one launch = one decoder layer's attention for all batch rows: "
                                    "K and V rows of every row's context are streamed once)",

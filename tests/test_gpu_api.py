@@ -254,3 +254,28 @@ def test_slow_path_decoding_options(model, sd):
     c = model.transcribe_batch([pcm], max_tokens=10, ignore_eos=True, temperature=1.0, seed=4)[0]
     assert a == b and len(a) == 10 and all(0 <= x < QC.TEXT_TINY.vocab for x in a)
     assert a != c or a != greedy
+
+
+def test_streaming_asr_batched_equals_sequential(model):
+    """StreamingASR mirror (qasr/streaming.py) on the engine: bursts of signal separated by silence, an energy VAD in
+    place of Silero (a separate model, out of scope); all segments in one ragged batch == one transcribe per segment."""
+    from qasr import streaming as S
+    vocab, merges = _bpe_fixture()
+    model.set_vocab({i: t for t, i in vocab.items()})
+    model.set_merges(merges)
+    parts = []
+    for k, (sec, gap) in enumerate(((1.3, 0.5), (2.2, 0.4), (0.2, 0.6), (3.1, 0.3))):      # the 0.2 s blip is below minSpeechDuration
+        parts += [synth.synth_waveform(k, sec), np.zeros(int(gap * 16000), np.float32)]
+    audio = np.concatenate(parts)
+
+    def energy_vad(chunk):
+        return 0.9 if float(np.sqrt(np.mean(chunk * chunk))) > 0.05 else 0.02
+    cfg = S.StreamingASRConfig(max_tokens=6, max_segment_duration=2.5, language="English")
+    st = S.StreamingASR(model, energy_vad)
+    seq = list(st.transcribe_stream(audio, config=cfg))
+    bat = st.transcribe_stream_batched(audio, config=cfg)
+    assert bat == seq
+    assert len(seq) >= 4 and all(s.is_final for s in seq)                # 3 bursts, the 3.1 s one force-split at 2.5 s
+    assert [s.segment_index for s in seq] == list(range(len(seq)))
+    # (after a force-split the closing segment still reports the VAD segment's own start time, as in the reference)
+    assert all(seq[i].end_time > seq[i - 1].end_time for i in range(1, len(seq)))
