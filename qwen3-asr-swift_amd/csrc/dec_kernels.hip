@@ -633,7 +633,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     // Zeroing right after the loads makes the wait for X precede the weight loads on purpose: measured in the real
     // decode step (cold weights from HBM), issuing the weight stream -- or even just the norm weights -- ahead of that
     // wait is SLOWER (decode 149.3 -> 157.6 / 151.1 ms at B=32) although a warm-cache probe of the kernel alone gets
-    // faster: the L1 returns data in order across the waves of a CU, so early HBM misses delay the other waves' X.
+    // faster; the same holds for the copy-prologue kernels alone (o-proj / down: decode 145.9 -> 149.7 ms).  X is on the
+    // critical path (staging + barrier) and, after a kernel boundary, is itself a fabric read: with the weight stream
+    // queued right behind it, the X reads of later waves wait behind the weight misses of earlier ones.
     auto mask_x = [&](int r0) {
         if (r0 + srow >= a.B) {
 #pragma unroll

@@ -411,18 +411,26 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         KVLayout kv{kcache_[l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
         kv.k += kv.off(r0, 0, 0);
         kv.vf += kv.off(r0, 0, 0);
+        // diagnostic (make DIAG=1): in-situ phase stamps of ONE layer's five launches inside a real step
+        unsigned long long* dbg = (stamp_buf_ && l == stamp_layer_) ? stamp_buf_ : nullptr;
+        const size_t dbg_stride = (size_t)512 * 16 * 8;
         DecGemvArgs a{};
         a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
+        decode_gemv_set_debug(dbg);
         decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, h, s);
         const RopeRows rr = rope_rows(r0);
         decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
-                                rr.cos_rows, rr.sin_rows, kv, at, s);
+                                rr.cos_rows, rr.sin_rows, kv, at, s, dbg ? dbg + 4 * dbg_stride : nullptr);
         a.W = L.wo; a.Wp = L.wo_p; a.X = at; a.N = H; a.K = nq; a.out = x;
+        decode_gemv_set_debug(dbg ? dbg + dbg_stride : nullptr);
         decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
         a.W = L.wgu; a.Wp = L.wgu_p; a.X = x; a.N = 2 * I; a.K = H; a.out = act;
+        decode_gemv_set_debug(dbg ? dbg + 2 * dbg_stride : nullptr);
         decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, h, s);
         a.W = L.wdown; a.Wp = L.wdown_p; a.X = act; a.N = H; a.K = I; a.out = x;
+        decode_gemv_set_debug(dbg ? dbg + 3 * dbg_stride : nullptr);
         decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
+        decode_gemv_set_debug(nullptr);
     }
     if (!with_head) return;
     run_lm_head(want_logits, r0, nr, s);
@@ -738,6 +746,35 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                 "after sync %.2f | sweeps done %.2f | slot merge done %.2f | after sync %.2f | end %.2f | span %.2f\n", cnt,
                 acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100,
                 acc[5] / cnt / 100, acc[6] / cnt / 100, (double)(t6 - t0) / 100);
+    }
+    if (which == 0 && getenv("QASR_STAMPS_INSITU")) {
+        // one real decode step (eager, all layers, cold weights) with layer 14's five launches stamped
+        DevBuf d;
+        const size_t stride = (size_t)512 * 16 * 8, n = 5 * stride;
+        d.alloc(n * sizeof(unsigned long long));
+        std::vector<unsigned long long> hst(n);
+        const char* names[5] = {"qkv (norm)", "o-proj (resid)", "gate/up (norm, swiglu)", "down (resid)", "attention"};
+        for (int rep = 0; rep < 2; ++rep) {
+            QASR_HIP(hipMemsetAsync(d.p, 0, d.bytes, s));
+            stamp_buf_ = d.as<unsigned long long>();
+            stamp_layer_ = cfg_.dec_layers / 2;
+            run_decode_step(false, false, 0, rows, s, true);
+            stamp_buf_ = nullptr;
+            QASR_HIP(hipMemcpyAsync(hst.data(), d.p, d.bytes, hipMemcpyDeviceToHost, s));
+            QASR_HIP(hipStreamSynchronize(s));
+            unsigned long long first = ~0ull;
+            for (size_t i = 0; i < n; i += 8) if (hst[i]) first = std::min(first, hst[i]);
+            for (int k : {0, 4, 1, 2, 3}) {
+                unsigned long long t0 = ~0ull, t1 = 0;
+                const unsigned long long* h = hst.data() + k * stride;
+                for (size_t i = 0; i < stride; i += 8) if (h[i]) { t0 = std::min(t0, h[i]); for (int q = 0; q < 7; ++q) t1 = std::max(t1, h[i + q]); }
+                double acc[7] = {0}; int cnt[7] = {0};
+                for (size_t i = 0; i < stride; i += 8) if (h[i]) for (int q = 0; q < 7; ++q) if (h[i + q]) { acc[q] += (double)(h[i + q] - t0); ++cnt[q]; }
+                fprintf(stderr, "[qasr] in-situ %-24s starts at %.2f us, span %.2f us; mean stamps:", names[k], (double)(t0 - first) / 100, (double)(t1 - t0) / 100);
+                for (int q = 0; q < 7; ++q) fprintf(stderr, " %.2f", cnt[q] ? acc[q] / cnt[q] / 100 : 0.0);
+                fprintf(stderr, "\n");
+            }
+        }
     }
     if (which == 0 && getenv("QASR_GEMV_STAMPS")) {
         DevBuf d;

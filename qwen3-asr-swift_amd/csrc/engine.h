@@ -210,6 +210,8 @@ private:
     int max_prompt_ = 0, max_ctx_ = 0, max_pos_ = 0, vt_stride_ = 0;
     DevBuf d_rope_cos_, d_rope_sin_, d_rope_rows_;    // tables [max_ctx][hd/2]; per-row copies for the next step
     std::vector<std::unique_ptr<DevBuf>> kcache_, vfcache_;     // per layer: keys row-major, values fragment-major
+    unsigned long long* stamp_buf_ = nullptr;                   // diagnostic in-situ stamps (kernel_probe, make DIAG=1)
+    int stamp_layer_ = -1;
     DevBuf d_al_rows_, d_al_x_, d_al_logits_, d_al_idx_;         // aligner head workspace (grown on demand)
     DevBuf d_vrows_;                                            // row-major V of one layer (prompt-pass scratch)
     DevBuf d_vt_;
