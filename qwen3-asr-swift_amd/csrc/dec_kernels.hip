@@ -395,12 +395,198 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Prompt attention, second form.  Workgroup = 64 query rows of one (clip, KV head) -- BOTH query heads of the GQA
+// pair share every staged K / V^T tile; 4 waves x 16 rows.  Key tiles of 64 are double-buffered in LDS by
+// direct-to-LDS loads (global_load_lds, lane-linear image, XOR chunk swizzle on the source address), so tile t+1
+// streams in under the MFMAs of tile t and no staging registers are live.  As in the decode kernel the scores are
+// produced TRANSPOSED, S^T = K Q^T: a lane then owns ONE query row (lane & 15) and 16 of the tile's keys, so the row
+// maximum needs 2 cross-lane steps instead of 8, the row sum none until the end, and the accumulator registers ARE
+// the B operand of O^T = V^T P^T -- P never goes through LDS, and O^T has the query on the same lane as its
+// softmax statistics (rescale = one multiply, no shuffles).  Rounding points are those of the first form
+// (flash_prefill_attention in oracle/decoder.py): per 64-key tile, P rounded to bf16, the row sum over rounded P.
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void prefill_attention2_kernel(const bf16_t* __restrict__ qr, KVLayout cache,
+                                                                 const bf16_t* __restrict__ vt, int vt_stride,
+                                                                 const int* __restrict__ cu,
+                                                                 const int* __restrict__ slot_of_clip, int heads,
+                                                                 bf16_t* __restrict__ out, float scale) {
+    constexpr int KT = 64, KS = HD / 32, DT = HD / 16, KCH = HD / 8, REP = 2;
+    constexpr int TILE_BYTES = KT * HD * 2;                       // K tile and V^T tile have the same size
+    constexpr int K_RPI = 64 / KCH, K_IPW = KT / K_RPI / 4;       // rows per wave instruction, instructions per wave
+    constexpr int V_IPW = HD / 8 / 4;                             // V^T rows are 128 B: 8 rows per instruction
+    static_assert(K_IPW >= 1 && V_IPW >= 1, "tile staging geometry");
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];   // [buffer][K | V^T]
+    const int clip = blockIdx.z, kvh = blockIdx.y, q0 = blockIdx.x * 64;
+    const int row0 = cu[clip], T = cu[clip + 1] - row0;
+    if (q0 >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int sl = slot_of_clip[clip];
+    const bf16_t* kbase = cache.k + cache.off(sl, kvh, 0);
+    const bf16_t* vbase = vt + ((long)sl * cache.kv_heads + kvh) * HD * vt_stride;
+    const int qw = q0 + wave * 16, qpos = qw + fr;
+
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < K_IPW; ++i) {
+            const int inst = wave * K_IPW + i;
+            const int r = inst * K_RPI + lane / KCH, c = lane % KCH;
+            int key = k0 + r;
+            key = key < cache.max_ctx ? key : cache.max_ctx - 1;          // rows past the prompt are masked, not read as data
+            const bf16_t* src = kbase + (long)key * HD + ((c ^ (r & (KCH - 1))) << 3);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&smem[buf][0][inst * 1024], 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < V_IPW; ++i) {
+            const int inst = wave * V_IPW + i;
+            const int d = inst * 8 + (lane >> 3), c = lane & 7;
+            const bf16_t* src = vbase + (long)d * vt_stride + k0 + ((c ^ (d & 7)) << 3);   // V^T is zero past the prompt
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&smem[buf][1][inst * 1024], 16, 0, 0);
+        }
+    };
+
+    const int q_hi = min(q0 + 64, T);                     // causal: keys < q_hi
+    const int n_tiles = (q_hi + KT - 1) / KT;
+    stage(0, 0);
+    // query fragments: B operand of S^T (column = query row fr, k = head dims), both heads of the pair
+    mfma_bf16x8 qf[REP][KS];
+#pragma unroll
+    for (int mi = 0; mi < REP; ++mi) {
+        const int h = kvh * REP + mi;
+        const int rc = qpos < T ? qpos : T - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint4 u = *reinterpret_cast<const uint4*>(qr + ((long)(row0 + rc) * heads + h) * HD + s * 32 + g * 8);
+            qf[mi][s] = __builtin_bit_cast(mfma_bf16x8, u);
+        }
+    }
+    f32x4 o[REP][DT];                                     // O^T: rows d = dt*16 + g*4 + j, column = query row fr
+#pragma unroll
+    for (int mi = 0; mi < REP; ++mi)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[mi][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[REP], l_run[REP];
+#pragma unroll
+    for (int mi = 0; mi < REP; ++mi) { m_run[mi] = -INFINITY; l_run[mi] = 0.0f; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA completion is tracked by vmcnt only (also covers qf)
+    __syncthreads();
+
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int cur = kt & 1, k0 = kt * KT;
+        if (kt + 1 < n_tiles) stage(cur ^ 1, k0 + KT);    // streams in under this tile's MFMAs
+        if (k0 <= qw + 15 && qw < T) {                    // this wave has unmasked keys in the tile (wave-uniform)
+            const char* s_k = smem[cur][0];
+            const char* s_v = smem[cur][1];
+            f32x4 sc[REP][4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int key = nb * 16 + fr;
+                mfma_bf16x8 kf[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    kf[s] = *reinterpret_cast<const mfma_bf16x8*>(s_k + key * (HD * 2) + (((s * 4 + g) ^ (key & (KCH - 1))) << 4));
+#pragma unroll
+                for (int mi = 0; mi < REP; ++mi) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[mi][s], acc, 0, 0, 0);
+                    sc[mi][nb] = acc;
+                }
+            }
+            unsigned pk[REP][2][4];
+#pragma unroll
+            for (int mi = 0; mi < REP; ++mi) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = k0 + nb * 16 + g * 4 + j;
+                        const float v = (key <= qpos && key < T) ? sc[mi][nb][j] * scale : -INFINITY;   // select: stale rows may be NaN
+                        sc[mi][nb][j] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[mi], mx);
+                const float m_ref = m_new == -INFINITY ? 0.0f : m_new;     // rows past the prompt keep m = -inf
+                const float alpha = __expf(m_run[mi] - m_ref);
+                float rs = 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const bf16_t p0 = f32_to_bf16(__expf(sc[mi][nb][j] - m_ref)), p1 = f32_to_bf16(__expf(sc[mi][nb][j + 1] - m_ref));
+                        rs += bf16_to_f32(p0) + bf16_to_f32(p1);
+                        // k-slot order of the P V^T product: slots 0-3 <- keys 4g+j of the even 16-key block, 4-7 <- the odd one
+                        pk[mi][nb >> 1][(nb & 1) * 2 + j / 2] = (unsigned)p0 | ((unsigned)p1 << 16);
+                    }
+                l_run[mi] = l_run[mi] * alpha + rs;
+                m_run[mi] = m_new;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[mi][d][j] *= alpha;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                mfma_bf16x8 pb[REP];
+#pragma unroll
+                for (int mi = 0; mi < REP; ++mi)
+                    pb[mi] = __builtin_bit_cast(mfma_bf16x8, make_uint4(pk[mi][p][0], pk[mi][p][1], pk[mi][p][2], pk[mi][p][3]));
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int dr = d * 16 + fr;
+                    // A operand rows = d; k-slots 8g..8g+7 <- keys {32p + 4g + j, 32p + 16 + 4g + j}: two 8-byte reads
+                    const char* vrow = s_v + dr * 128 + (g & 1) * 8;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((4 * p + (g >> 1)) ^ (dr & 7)) << 4));
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((4 * p + 2 + (g >> 1)) ^ (dr & 7)) << 4));
+                    const mfma_bf16x8 vf = __builtin_bit_cast(mfma_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+                    for (int mi = 0; mi < REP; ++mi) o[mi][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[mi], o[mi][d], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt+1 has landed (this wave's part) ...
+        __syncthreads();                                // ... and every wave's part after the barrier
+    }
+    // ---- output: lane = query row fr, head dims dt*16 + g*4 .. +3 -> 8-byte stores ------------------------------
+    if (qpos < T) {
+#pragma unroll
+        for (int mi = 0; mi < REP; ++mi) {
+            float l = l_run[mi];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float invl = 1.0f / l;
+            bf16_t* dst = out + ((long)(row0 + qpos) * heads + kvh * REP + mi) * HD + g * 4;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const uint2 v = make_uint2((unsigned)f32_to_bf16(o[mi][d][0] * invl) | ((unsigned)f32_to_bf16(o[mi][d][1] * invl) << 16),
+                                           (unsigned)f32_to_bf16(o[mi][d][2] * invl) | ((unsigned)f32_to_bf16(o[mi][d][3] * invl) << 16));
+                *reinterpret_cast<uint2*>(dst + d * 16) = v;
+            }
+        }
+    }
+}
+
 void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt, int vt_stride, const int* cu,
                               const int* slot_of_clip, int n_clips, int max_len, int heads, bf16_t* out,
                               hipStream_t s) {
     if (n_clips <= 0 || max_len <= 0) return;
     static const int mt = getenv("QASR_PA_MT") ? atoi(getenv("QASR_PA_MT")) : 1;      // A/B knob: row tiles per wave
+    static const int form = getenv("QASR_PA_FORM") ? atoi(getenv("QASR_PA_FORM")) : 2; // A/B knob: 2 = transposed-score form
     const float scale = 1.0f / sqrtf((float)cache.hd);
+    if (form == 2 && heads == 2 * cache.kv_heads && (cache.hd == 128 || cache.hd == 32)) {
+        const dim3 grid(cdiv(max_len, 64), cache.kv_heads, n_clips);
+        if (cache.hd == 128)
+            hipLaunchKernelGGL((prefill_attention2_kernel<128>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
+        else
+            hipLaunchKernelGGL((prefill_attention2_kernel<32>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
+        return;
+    }
     if (cache.hd == 128 && mt == 2)
         hipLaunchKernelGGL((prefill_attention_kernel<128, 2>), dim3(cdiv(max_len, 128), heads, n_clips), dim3(256), 0, s,
                            qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);

@@ -2,7 +2,7 @@
 
 Tolerances: the classify logits are bf16 values produced after 2 (tiny) / 28 (full) decoder layers; the device differs
 from the oracle by f32 association order and the flash-tile rounding of P (oracle policy DEVICE restates it), so logits
-are compared within 4 bf16 ulps of the largest |logit| and rel-L2 < 3e-2 (the bound used for the ASR logits in
+are compared within 4 bf16 ulps of the largest |logit| and rel-L2 < 3e-2 (the bounds used for the ASR logits in
 test_gpu_full.py), and the raw class index must match wherever the oracle's top-2 margin exceeds that tolerance.
 Host logic (slots, LIS fix-up, seconds, alignLong driver) must match exactly given the same raw indices."""
 import numpy as np
@@ -18,7 +18,9 @@ TS_TINY = 506
 
 
 def _tol(ref):
-    return 4 * 2.0 ** -8 * float(np.abs(ref).max())
+    """4 bf16 ulps at the binade of the largest |logit| (a bf16 ulp there is 2^(floor(log2 max) - 7)).  The 300 000 logits of
+    the full-size case sit at 2 ulps typical / 2.7 ulps extreme for both prompt-attention forms (scratch/dbg_pa.py)."""
+    return 4 * 2.0 ** (np.floor(np.log2(float(np.abs(ref).max()))) - 7)
 
 
 def _check_logits(got, ref, raw):
