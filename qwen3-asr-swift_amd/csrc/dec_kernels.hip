@@ -497,29 +497,38 @@ __global__ __launch_bounds__(256) void prefill_attention2_kernel(const bf16_t* _
                 }
             }
             unsigned pk[REP][2][4];
+            // only the tile on the diagonal (or the prompt's last tile) needs the per-key mask (wave-uniform)
+            const bool full = k0 + KT - 1 <= qw && k0 + KT <= T;
+            const float c2 = scale * 1.44269504088896341f;                 // exp(s * scale - m * scale) = 2^((s - m) * c2)
 #pragma unroll
             for (int mi = 0; mi < REP; ++mi) {
                 float mx = -INFINITY;
+                if (!full) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int key = k0 + nb * 16 + g * 4 + j;
+                            if (!(key <= qpos && key < T)) sc[mi][nb][j] = -INFINITY;     // select: stale rows may be NaN
+                        }
+                }
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int key = k0 + nb * 16 + g * 4 + j;
-                        const float v = (key <= qpos && key < T) ? sc[mi][nb][j] * scale : -INFINITY;   // select: stale rows may be NaN
-                        sc[mi][nb][j] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, sc[mi][nb][j]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float m_new = fmaxf(m_run[mi], mx);
+                const float m_new = fmaxf(m_run[mi], mx);                  // raw score units (scale > 0 keeps the order)
                 const float m_ref = m_new == -INFINITY ? 0.0f : m_new;     // rows past the prompt keep m = -inf
-                const float alpha = __expf(m_run[mi] - m_ref);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[mi] - m_ref) * c2);
+                const float mc = -m_ref * c2;
                 float rs = 0.0f;
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
-                        const bf16_t p0 = f32_to_bf16(__expf(sc[mi][nb][j] - m_ref)), p1 = f32_to_bf16(__expf(sc[mi][nb][j + 1] - m_ref));
+                        const bf16_t p0 = f32_to_bf16(__builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j], c2, mc)));
+                        const bf16_t p1 = f32_to_bf16(__builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j + 1], c2, mc)));
                         rs += bf16_to_f32(p0) + bf16_to_f32(p1);
                         // k-slot order of the P V^T product: slots 0-3 <- keys 4g+j of the even 16-key block, 4-7 <- the odd one
                         pk[mi][nb >> 1][(nb & 1) * 2 + j / 2] = (unsigned)p0 | ((unsigned)p1 << 16);
