@@ -14,6 +14,8 @@ import numpy as np
 from . import _lib
 from .model import Qwen3ASRModel, QasrError, _fptr, _iptr
 
+QASR_ERR_UNSUPPORTED = 7     # include/qasr.h
+
 AlignedWord = namedtuple("AlignedWord", "text start_time end_time")     # AudioCommon/Protocols.swift AlignedWord
 
 
@@ -27,7 +29,7 @@ def split_word_pairs(text, language="English"):
     a, b = C.c_void_p(), C.c_void_p()
     n = lib.qasr_split_words(text.encode("utf-8"), language.encode("utf-8"), C.byref(a), C.byref(b))
     try:
-        if n == -7:
+        if n == -QASR_ERR_UNSUPPORTED:
             raise UnsupportedLanguage(language)
         if n < 0:
             raise QasrError(f"qasr_split_words failed ({n})")
