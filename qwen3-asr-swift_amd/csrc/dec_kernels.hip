@@ -1,6 +1,7 @@
 // dec_kernels.hip -- text-decoder kernels (see dec_kernels.h).
 #include "dec_kernels.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace qasr {
 
@@ -406,8 +407,11 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
 // softmax statistics (rescale = one multiply, no shuffles).  Rounding points are those of the first form
 // (flash_prefill_attention in oracle/decoder.py): per 64-key tile, P rounded to bf16, the row sum over rounded P.
 // ------------------------------------------------------------------------------------------------
+// amdgpu_waves_per_eu(2, 2): without it hipcc spreads the accumulators over 202 VGPRs + 78 AGPRs = 280 registers, which
+// leaves ONE wave per SIMD (hipOccupancyMaxActiveBlocksPerMultiprocessor = 1; SQ_WAVE_CYCLES showed 0.8 waves per SIMD);
+// capped at 256 it needs 204 VGPRs, no spills, two workgroups per CU.
 template <int HD>
-__global__ __launch_bounds__(256) void prefill_attention2_kernel(const bf16_t* __restrict__ qr, KVLayout cache,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_attention2_kernel(const bf16_t* __restrict__ qr, KVLayout cache,
                                                                  const bf16_t* __restrict__ vt, int vt_stride,
                                                                  const int* __restrict__ cu,
                                                                  const int* __restrict__ slot_of_clip, int heads,

@@ -337,6 +337,118 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same tile with ONE 32 KiB LDS buffer (two barriers per K-step, no software double buffering): 4-5 workgroups fit
+// a CU instead of 2, and the overlap of loads with MFMAs comes from the other resident workgroups.
+// ------------------------------------------------------------------------------------------------
+template <class ALoad, class Epi, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_glds1_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw,
+                                                                     int M, int N, int K, Epi epi,
+                                                                     const bf16_t* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) char smem[1][2][GEMM_BM * 128];   // ONE buffer: [A|B][row*128B] = 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbx = (N + GEMM_BN - 1) / GEMM_BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / nbx) * GEMM_BM, n0 = (bid % nbx) * GEMM_BN;
+
+    // staging: wave w, instruction i covers tile rows (w*4 + i)*8 .. +7; lane -> (row + lane/8, LDS slot lane%8)
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;              // source chunk = slot ^ (row & 7), rows are 8-aligned per group
+    typename ALoad::Row arow[4];
+    const bf16_t* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;
+        arow[i] = aload.row_init(m0 + r);
+        const int n = n0 + r;
+        wrow[i] = n < N ? Wt + (long)n * ldw : nullptr;
+    }
+    auto stage = [&](int buf, int kt) {
+        const int k = kt * GEMM_BK + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* pa = aload.addr(arow[i], k);
+            const bf16_t* pb = (wrow[i] && k < K) ? wrow[i] + k : nullptr;
+            const int off = (wave * 4 + i) * 1024;      // wave-uniform LDS base of this instruction
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa ? pa : zeros), (lds_ptr_t)&smem[buf][0][off], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb ? pb : zeros), (lds_ptr_t)&smem[buf][1][off], 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
+    const int fr = lane & 15, fc = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        stage(0, kt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA completion is tracked by vmcnt only
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            mfma_bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[0][0][gemm_lds_off(wm * 64 + i * 16 + fr, fc + 4 * s)]);
+                b[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[0][1][gemm_lds_off(wn * 64 + i * 16 + fr, fc + 4 * s)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                // every wave is done with the tile before it is overwritten
+    }
+
+    // epilogue in two 32-column halves: the wave's staging image is 64 rows x 32 floats = 8 KiB (4 waves = the 32 KiB)
+    float* ct = reinterpret_cast<float*>(&smem[0][0][0]) + wave * (64 * 32);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * 32 + jj * 16 + fr] = acc[i][2 * h + jj][r];
+        __syncthreads();
+        if (MODE == 0) {
+            const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + er;
+                const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * 32 + ec;
+                if (m < M && n < N) epi(m, n, *reinterpret_cast<const float4*>(&ct[row * 32 + ec]));
+            }
+        } else {
+            const int er = lane >> 2, e = (lane & 3) * 4;
+#pragma unroll 4
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 16 + er;
+                const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * 32;
+                if (m < M && n < N) {
+                    const float4 g = *reinterpret_cast<const float4*>(&ct[row * 32 + e]);
+                    const float4 u = *reinterpret_cast<const float4*>(&ct[row * 32 + 16 + e]);
+                    float4 v;
+                    v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
+                    v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
+                    epi(m, n / 2 + e, v);
+                }
+            }
+        }
+    }
+}
+
 // 256 bytes of zeros in HBM for masked direct-to-LDS chunks (one per translation unit)
 inline const bf16_t* gemm_zero_block() {
     static bf16_t* z = nullptr;
@@ -345,6 +457,12 @@ inline const bf16_t* gemm_zero_block() {
         QASR_HIP(hipMemset(z, 0, 256));
     }
     return z;
+}
+inline int gemm_nbuf() {
+    // LDS buffers of the glds kernel.  1 (default): 32 KiB + 124 VGPRs -> 4 workgroups per CU; measured against the
+    // double-buffered 64 KiB form (2 per CU): encoder 18.1 -> 15.6 ms, prompt pass 20.8 -> 18.9 ms at 32 x 30 s.
+    static const int v = getenv("QASR_GEMM_NBUF") ? atoi(getenv("QASR_GEMM_NBUF")) : 1;
+    return v;
 }
 inline bool gemm_use_glds() {
     static const int v = getenv("QASR_GEMM_GLDS") ? atoi(getenv("QASR_GEMM_GLDS")) : 1;
@@ -355,7 +473,10 @@ template <class ALoad, class Epi>
 inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    if (gemm_use_glds())
+    if (gemm_use_glds() && gemm_nbuf() == 1)
+        hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block());
+    else if (gemm_use_glds())
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
     else
@@ -367,7 +488,10 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
     if (M <= 0 || N <= 0) return;
     if (N % 32 != 0) throw std::invalid_argument("swiglu gemm: fused width must be a multiple of 32");
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    if (gemm_use_glds())
+    if (gemm_use_glds() && gemm_nbuf() == 1)
+        hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block());
+    else if (gemm_use_glds())
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
     else
