@@ -458,11 +458,15 @@ inline const bf16_t* gemm_zero_block() {
     }
     return z;
 }
-inline int gemm_nbuf() {
-    // LDS buffers of the glds kernel.  1 (default): 32 KiB + 124 VGPRs -> 4 workgroups per CU; measured against the
-    // double-buffered 64 KiB form (2 per CU): encoder 18.1 -> 15.6 ms, prompt pass 20.8 -> 18.9 ms at 32 x 30 s.
-    static const int v = getenv("QASR_GEMM_NBUF") ? atoi(getenv("QASR_GEMM_NBUF")) : 1;
-    return v;
+// LDS buffers of the glds kernel for a launch of `grid` tiles.  1: 32 KiB + 124 VGPRs -> 4 workgroups per CU, the loads
+// of one overlap the MFMAs of the others (encoder 18.1 -> 15.6 ms, prompt pass 20.8 -> 18.9 ms at 32 x 30 s against the
+// double-buffered 64 KiB form at 2 per CU).  That only works when there ARE several workgroups per CU: small launches
+// (1 clip: 32-192 tiles; the aligner's 200-tile encoder GEMMs) ran 10-25 % slower with it, so they keep the
+// software-double-buffered form.  QASR_GEMM_NBUF=1|2 forces one form (A/B).
+inline int gemm_nbuf(int grid) {
+    static const int v = getenv("QASR_GEMM_NBUF") ? atoi(getenv("QASR_GEMM_NBUF")) : 0;
+    if (v == 1 || v == 2) return v;
+    return grid >= 640 ? 1 : 2;             // 2.5 tiles per CU on the 256-CU part (686-tile launches measured faster with 1)
 }
 inline bool gemm_use_glds() {
     static const int v = getenv("QASR_GEMM_GLDS") ? atoi(getenv("QASR_GEMM_GLDS")) : 1;
@@ -473,7 +477,7 @@ template <class ALoad, class Epi>
 inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    if (gemm_use_glds() && gemm_nbuf() == 1)
+    if (gemm_use_glds() && gemm_nbuf(grid) == 1)
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
     else if (gemm_use_glds())
@@ -488,7 +492,7 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
     if (M <= 0 || N <= 0) return;
     if (N % 32 != 0) throw std::invalid_argument("swiglu gemm: fused width must be a multiple of 32");
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    if (gemm_use_glds() && gemm_nbuf() == 1)
+    if (gemm_use_glds() && gemm_nbuf(grid) == 1)
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
     else if (gemm_use_glds())
