@@ -82,7 +82,8 @@ struct AConv3x3s2 {
     }
     __device__ __forceinline__ const bf16_t* addr(const Row& r, int k) const {
         if (k >= K) return nullptr;
-        int tap = k / C, ci = k - tap * C;
+        // k / C without an integer division (C is a run-time value): exact for k < 2^20 with the rounded-up reciprocal
+        int tap = (int)__umulhi((unsigned)k, (0xffffffffu / (unsigned)C) + 1u), ci = k - tap * C;
         if (!((r.mask >> tap) & 1u)) return nullptr;
         int kh = tap / 3, kw = tap - kh * 3;
         return r.base + ((long)kh * W + kw) * C + ci;
