@@ -794,12 +794,20 @@ struct DecGemv2Args {
     const bf16_t* norm_w;      // RMSNORM prologue: weight [K]
     float eps;
     unsigned long long* dbg;   // diagnostic phase stamps (see decode_gemv_stamps), null in product launches
+    int row_groups;            // > 1: gridDim.y groups of rows_per_group batch rows (see gemv2_nb)
+    int rows_per_group;
 };
 
 template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    const DecGemvArgs& a = a2.g;
+    DecGemvArgs a = a2.g;
+    if (gridDim.y > 1) {          // batch rows split over blockIdx.y in groups of 16 * NB (BF16 / RESID epilogues only)
+        const int rpg = a2.rows_per_group, r0 = blockIdx.y * rpg;
+        a.X += (long)r0 * a.K;
+        a.out += (long)r0 * (EPI == DEC_EPI_SWIGLU ? a.N / 2 : a.N);
+        a.B = a.B - r0 < rpg ? a.B - r0 : rpg;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
     constexpr int K = KSW * WAVES * 32;                           // host checks a.K == K
     constexpr int KCH = K / 8;                                    // 16-byte chunks per row
@@ -1028,7 +1036,7 @@ static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
             QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT)), dim3(WAVES * 64), lds, s, a2);
+        hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), a2.row_groups > 1 ? a2.row_groups : 1), dim3(WAVES * 64), lds, s, a2);
         return true;
     }
 }
@@ -1036,6 +1044,18 @@ static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
 template <int NT, int WAVES, int KSW, int PRO, int EPI>
 static bool gemv2_nb(const DecGemv2Args& a2, hipStream_t s) {
     const int nb = (a2.g.B + 15) / 16;
+    // One workgroup per (row tile, 16 batch rows) -- gridDim.y row groups -- instead of one workgroup walking all batch tiles:
+    // twice the workgroups at 32 rows, half the activation bytes (and RMSNorm work) per workgroup, no second staging phase
+    // for the K = 3072 matrix.  Measured in the real step, decode at 32 x 30 s: 148.8 ms unsplit, 140.2 ms with only the two
+    // residual GEMVs (64 -> 128 workgroups) split, 137.3 ms with all four; 8-row groups (151 ms) and 4-wave workgroups
+    // (140 ms) lose.  QASR_GEMV_SPLITB=0|1|2 selects none | residual only | all (A/B).
+    static const int split_b = getenv("QASR_GEMV_SPLITB") ? atoi(getenv("QASR_GEMV_SPLITB")) : 2;
+    if (nb > 1 && EPI != DEC_EPI_LOGITS && ((split_b == 1 && EPI == DEC_EPI_RESID) || split_b == 2)) {
+        DecGemv2Args b2 = a2;
+        b2.rows_per_group = 16;
+        b2.row_groups = nb;
+        return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI>(b2, s);
+    }
     // all batch rows resident in LDS when they fit (LDS and staging registers), else 16 rows per phase
     constexpr bool fit2 = gemv2_lds<NT, 2, WAVES, KSW, true>() <= 150 * 1024 && NT * KSW * 4 + 2 * KSW * 4 <= 170;
     switch (nb) {
@@ -1074,7 +1094,7 @@ int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* nor
                              hipStream_t s) {
     if (a.B <= 0) return 0;
     const int nt = dec_nt(epi, a.N);
-    DecGemv2Args a2{a, norm_w, eps, g_gemv_dbg};
+    DecGemv2Args a2{a, norm_w, eps, g_gemv_dbg, 1, 16};
     bool ok = false;
     if (a.Wp && a.N % (16 * nt) == 0 && a.B <= 64) {
         if (norm_w) {
