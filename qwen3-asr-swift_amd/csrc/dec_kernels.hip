@@ -138,6 +138,71 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     *reinterpret_cast<unsigned*>(dst + HALF + 2 * j) = (unsigned)f32_to_bf16(o2a) | ((unsigned)f32_to_bf16(o2b) << 16);
 }
 
+// Wide form: a head lives on HD/16 lanes, each owning 8 consecutive elements of the first half and the matching 8 of the
+// second half (16-byte accesses); a wave covers 64 / (HD/16) heads.  Same arithmetic per element as the form above; a
+// quarter of the waves (the narrow form's 208 000 four-byte-per-lane waves per launch were bound by wave launch rate).
+template <int HD>
+__global__ __launch_bounds__(256) void qk_norm_rope_wide_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ slot,
+                                                                const int* __restrict__ pos, int n_pos, int heads,
+                                                                int kv_heads, const bf16_t* __restrict__ qn_w,
+                                                                const bf16_t* __restrict__ kn_w, float eps,
+                                                                const float* __restrict__ rope_cos,
+                                                                const float* __restrict__ rope_sin, bf16_t* __restrict__ qr,
+                                                                KVLayout cache) {
+    constexpr int LPH = HD / 16, HPW = 64 / LPH, HALF = HD / 2;
+    const int nh = heads + 2 * kv_heads;
+    const int groups = nh / HPW;                        // head groups per position (host checks nh % HPW == 0)
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long)n_pos * groups) return;
+    const int p = (int)(wid / groups), h = (int)(wid - (long)p * groups) * HPW + lane / LPH;
+    const int j = lane % LPH;
+    const bf16_t* src = qkv + (long)p * nh * HD + (long)h * HD;
+    const int sl = slot[p], ps = pos[p];
+    const uint4 a = *reinterpret_cast<const uint4*>(src + 8 * j);
+    const uint4 b = *reinterpret_cast<const uint4*>(src + HALF + 8 * j);
+    if (h >= heads + kv_heads) {                        // V: plain copy (the transposed image is built separately)
+        bf16_t* dv = cache.v + cache.off(sl, h - heads - kv_heads, ps);
+        *reinterpret_cast<uint4*>(dv + 8 * j) = a;
+        *reinterpret_cast<uint4*>(dv + HALF + 8 * j) = b;
+        return;
+    }
+    const bf16_t* ae = reinterpret_cast<const bf16_t*>(&a);
+    const bf16_t* be = reinterpret_cast<const bf16_t*>(&b);
+    float x1[8], x2[8], ss = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        x1[e] = bf16_to_f32(ae[e]);
+        x2[e] = bf16_to_f32(be[e]);
+        ss += x1[e] * x1[e] + x2[e] * x2[e];
+    }
+#pragma unroll
+    for (int ofs = 1; ofs < LPH; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+    const float inv = rsqrtf(ss / (float)HD + eps);
+    const bf16_t* nw = h < heads ? qn_w : kn_w;
+    const uint4 w1 = *reinterpret_cast<const uint4*>(nw + 8 * j), w2 = *reinterpret_cast<const uint4*>(nw + HALF + 8 * j);
+    const bf16_t* w1e = reinterpret_cast<const bf16_t*>(&w1);
+    const bf16_t* w2e = reinterpret_cast<const bf16_t*>(&w2);
+    const float4* cp = reinterpret_cast<const float4*>(rope_cos + (long)ps * HALF + 8 * j);
+    const float4* sp = reinterpret_cast<const float4*>(rope_sin + (long)ps * HALF + 8 * j);
+    const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    uint4 o1, o2;
+    bf16_t* o1e = reinterpret_cast<bf16_t*>(&o1);
+    bf16_t* o2e = reinterpret_cast<bf16_t*>(&o2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float r1, r2;
+        norm_rope_pair(x1[e], x2[e], bf16_to_f32(w1e[e]), bf16_to_f32(w2e[e]), inv, cs[e], sn[e], r1, r2);
+        o1e[e] = f32_to_bf16(r1);
+        o2e[e] = f32_to_bf16(r2);
+    }
+    bf16_t* dst = h < heads ? qr + ((long)p * heads + h) * HD : cache.k + cache.off(sl, h - heads, ps);
+    *reinterpret_cast<uint4*>(dst + 8 * j) = o1;
+    *reinterpret_cast<uint4*>(dst + HALF + 8 * j) = o2;
+}
+
 // V^T image for the prompt pass: cache.v rows [pos][HD] -> vt[slot][kvh][d][pos], 64 positions per workgroup,
 // transposed through LDS so both sides move 128-byte rows.
 template <int HD>
@@ -189,7 +254,14 @@ void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int
                          const int* slot_of_clip, int n_clips, int max_len, hipStream_t s) {
     if (n_pos <= 0) return;
     const int nh = heads + 2 * kv_heads;
-    if (hd == 128 && nh % 2 == 0) {
+    static const int wide = getenv("QASR_QKNR_WIDE") ? atoi(getenv("QASR_QKNR_WIDE")) : 1;      // A/B knob
+    if (hd == 128 && nh % 8 == 0 && wide) {
+        long waves = (long)n_pos * (nh / 8);
+        hipLaunchKernelGGL(qk_norm_rope_wide_kernel<128>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
+                           kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache);
+        if (vt) hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(cdiv(max_len, 64), kv_heads, n_clips), dim3(256), 0, s,
+                                   cache, cu, slot_of_clip, vt, vt_stride);
+    } else if (hd == 128 && nh % 2 == 0) {
         long waves = (long)n_pos * (nh / 2);
         hipLaunchKernelGGL(qk_norm_rope_kernel<128>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
                            kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache);
