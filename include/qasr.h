@@ -187,6 +187,14 @@ int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps);
  * 1 = decode attention, 2 = LM head; 3 / 4 = prompt-pass QKV / gate-up GEMM (bytes_per_launch then holds FLOPs). */
 int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch);
 
+/* ---- tuning / diagnostic knobs ----------------------------------------------------------------
+ * Process-wide A/B switches between kept kernel variants (csrc/tuning.h lists them with their measurements: "gemm_nbuf",
+ * "gemv_splitb", "use_graph", ...).  Defaults are the measured winners; every value passes the parity tests.  Each knob
+ * is also seeded once from the environment variable QASR_<KEY IN UPPER CASE>.  No reference counterpart.
+ * QASR_ERR_INVALID: unknown key. */
+int qasr_set_tuning(const char* key, int value);
+int qasr_get_tuning(const char* key, int* value);
+
 /* ---- stage entry points (oracle diffing) -------------------------------------------------- */
 int qasr_num_mel_frames(size_t n_samples);              /* frames handed to the encoder */
 int qasr_num_audio_tokens(const qasr_engine* e, int n_frames);
@@ -205,7 +213,9 @@ int qasr_decode_forced(qasr_engine* e, const int32_t* tokens, int n, float* logi
  * Replaces Qwen3ForcedAligner.align / alignLong (Sources/Qwen3ASR/ForcedAligner.swift:226-331, :97-180):
  * mel -> audio encoder -> ONE decoder pass over [chat template + audio + text with <timestamp> slots] (no cache,
  * no autoregression) -> Linear(hidden, classify_num) at the slots -> argmax -> LIS monotonicity fix-up -> seconds.
- * Engines are created from the "aligner-0.6B" preset (encoder = the reference's `.forcedAligner` config). */
+ * Engines are created from the "aligner-0.6B" preset (encoder = the reference's `.forcedAligner` config); its default
+ * capacity max_audio_seconds = 1200 is the reference's own mel cap (AudioPreprocessing.swift:299-313), longer clips
+ * return QASR_ERR_CAPACITY. */
 typedef struct qasr_aligned_word {     /* AlignedWord (Sources/AudioCommon/Protocols.swift) */
     const char* text;                  /* surface form: the word with its adjacent punctuation */
     float start_time, end_time;        /* seconds */

@@ -80,8 +80,22 @@ def _w(sd, key):
     return sd(key) if callable(sd) else sd[key].to(torch.float32)
 
 
+# Summation-order probe (tests only): with FLIP_K set, every contraction runs over the reversed K axis -- the same
+# mathematical sum associated differently in f32.  Two CPU evaluations that differ only in this flag measure how far
+# bf16 rounding flips spread through the layers for reasons that have nothing to do with the device
+# (tests/test_gpu_encoder.py: distributional bound).
+FLIP_K = False
+
+
+def _mm(x, w):
+    """x [.., K] @ w[N, K]^T"""
+    if FLIP_K:
+        return x.flip(-1) @ w.flip(-1).T
+    return x @ w.T
+
+
 def _linear(x, sd, prefix, bias=True):
-    y = x @ _w(sd, prefix + ".weight").T
+    y = _mm(x, _w(sd, prefix + ".weight"))
     if bias:
         y = y + _w(sd, prefix + ".bias")
     return y
@@ -106,11 +120,13 @@ def conv_stem(mel, sd, cfg: AudioEncoderConfig, pol: P.Policy):
         w = _w(sd, f"audio_tower.{name}.weight").permute(0, 3, 1, 2)   # [o,kh,kw,i]->[o,i,kh,kw]
         b = _w(sd, f"audio_tower.{name}.bias")
         xin = x if name == "conv2d1" else pol.enc(x)       # conv1 consumes f32 mel on device too
+        if FLIP_K and name != "conv2d1":
+            xin, w = xin.flip(1), w.flip(1)
         x = _gelu(Fn.conv2d(xin, w, b, stride=2, padding=1))
     x = pol.enc(x)
     n, c, f, t = x.shape                                    # [chunks, 480, 16, t']
     x = x.permute(0, 3, 1, 2).reshape(n, t, c * f)          # idx = c*16 + f   (:423-424)
-    x = x @ _w(sd, "audio_tower.conv_out.weight").T         # no bias (:261)
+    x = _mm(x, _w(sd, "audio_tower.conv_out.weight"))       # no bias (:261)
     x = x + sinusoid_pe(t, cfg.d_model)[None]               # PE restarts per chunk (:439)
     valid = [tokens_for_chunk(c_) for c_ in clens]
     return torch.cat([x[i, :v] for i, v in enumerate(valid)], dim=0), clens

@@ -237,7 +237,10 @@ Engine::SlottedText Engine::prepare_alignment(const std::vector<std::pair<std::s
 }
 
 // align (long_form = false) / alignLong (true) on pre-split words; fills al_words / al_raw, returns the pass count
-int Engine::align_words(const float* pcm, size_t n, const std::vector<std::pair<std::string, std::string>>& pairs_in, bool long_form) {
+// long_text: the caller's text (qasr_align_long); the re-alignment passes then re-split it exactly like the reference
+int Engine::align_words(const float* pcm, size_t n, const std::vector<std::pair<std::string, std::string>>& pairs_in, bool long_form,
+                        const std::string* long_text) {
+    std::string rem_text = long_text ? *long_text : std::string();
     al_words.clear();
     al_raw.clear();
     const float seg_t = cfg_.timestamp_segment_time;
@@ -278,10 +281,27 @@ int Engine::align_words(const float* pcm, size_t n, const std::vector<std::pair<
         const size_t split_sample = (size_t)(split_time * 16000.0f);
         if (split_sample >= len) break;
         if ((float)(len - split_sample) / 16000.0f < min_chunk_s) break;
-        // the reference re-splits the remaining TEXT on spaces and drops `plateau` words; with the default splitter a
-        // kept word is one whitespace-separated token unless it is a Han ideograph -- drop the same number of pairs
-        if ((size_t)plateau >= pairs.size()) break;
-        pairs.erase(pairs.begin(), pairs.begin() + plateau);
+        if (long_text) {
+            // ForcedAligner.swift:162-165: the remaining TEXT is split on single spaces (empty pieces dropped), the first
+            // `plateau` pieces go, and the rest is joined and split into words again by the next align pass.  That is not
+            // the same as dropping `plateau` aligned words when a punctuation-only piece was merged into its neighbour or a
+            // piece encodes to no token (tests/golden/kat_aligner.json: align_long_resplit).
+            std::vector<std::string> pieces;
+            for (size_t i = 0; i < rem_text.size();) {
+                size_t j = rem_text.find(' ', i);
+                if (j == std::string::npos) j = rem_text.size();
+                if (j > i) pieces.push_back(rem_text.substr(i, j - i));
+                i = j + 1;
+            }
+            if ((size_t)plateau >= pieces.size()) break;
+            rem_text.clear();
+            for (size_t i = (size_t)plateau; i < pieces.size(); ++i) { if (!rem_text.empty()) rem_text += ' '; rem_text += pieces[i]; }
+            pairs = aligner_split_word_pairs(rem_text);
+        } else {
+            // caller-split words (no text to re-split): drop the aligned words themselves
+            if ((size_t)plateau >= pairs.size()) break;
+            pairs.erase(pairs.begin(), pairs.begin() + plateau);
+        }
         audio += split_sample;
         len -= split_sample;
         offset += split_time;

@@ -21,6 +21,7 @@ static int fail(qasr_engine* e, int code, const std::string& msg) {
 #define QASR_GUARD(e, body)                                                          \
     try { body; return QASR_OK; }                                                    \
     catch (const qasr::HipError& ex) { return fail(e, QASR_ERR_HIP, ex.what()); }    \
+    catch (const qasr::NotLoaded& ex) { return fail(e, QASR_ERR_NOT_LOADED, ex.what()); } \
     catch (const std::invalid_argument& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); } \
     catch (const std::length_error& ex) { return fail(e, QASR_ERR_CAPACITY, ex.what()); }    \
     catch (const std::exception& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); }
@@ -63,7 +64,7 @@ int qasr_default_config(const char* preset, qasr_config* c) {
         c->enc_d_model = 1024; c->enc_heads = 16; c->enc_ffn = 4096; c->enc_layers = 24; c->enc_out_dim = 1024;
         c->classify_num = 5000;
         c->bits = contains(lower_p, "bf16") || contains(lower_p, "float") ? 16 : contains(lower_p, "8bit") ? 8 : 4;   // ForcedAlignerVariant.detect :17-26
-        c->max_batch = 1; c->max_audio_seconds = 300; c->max_new_tokens = 1; c->max_prompt_extra = 4096;
+        c->max_batch = 1; c->max_audio_seconds = 1200; c->max_new_tokens = 1; c->max_prompt_extra = 4096;
         return QASR_OK;
     }
     // ASRModelSize.detect / detectBits (Qwen3ASR.swift:581-601)
@@ -162,6 +163,7 @@ int qasr_batch_rewind(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GU
 int qasr_batch_sync(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_sync()); }
 int qasr_batch_tokens(qasr_engine* e, int32_t* tokens, int32_t* lens) {
     if (!e || !tokens || !lens) return QASR_ERR_INVALID;
+    if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
     QASR_GUARD(e, e->impl->batch_tokens(tokens, lens));
 }
 int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps) {
@@ -294,12 +296,14 @@ int qasr_align_raw(qasr_engine* e, const float* pcm, size_t n, const int32_t* sl
 }
 
 static int align_common(qasr_engine* e, const float* pcm, size_t n, int sample_rate,
-                        const std::vector<std::pair<std::string, std::string>>& pairs, bool long_form, qasr_alignment* out) {
+                        const std::vector<std::pair<std::string, std::string>>& pairs, bool long_form, qasr_alignment* out,
+                        const char* long_text = nullptr) {
     if (sample_rate != 16000) return fail(e, QASR_ERR_INVALID, "input must be 16 kHz mono (no resampler: AVAudioConverter is not reproducible)");
     if (n == 0) return fail(e, QASR_ERR_EMPTY_AUDIO, "empty clip");
     if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
     QASR_GUARD(e, {
-        const int passes = e->impl->align_words(pcm, n, pairs, long_form);
+        const std::string text = long_text ? long_text : "";
+        const int passes = e->impl->align_words(pcm, n, pairs, long_form, long_text ? &text : nullptr);
         out->words = e->impl->al_view.data();
         out->n_words = e->impl->al_view.size();
         out->raw_indices = e->impl->al_raw.data();
@@ -323,7 +327,7 @@ int qasr_align_long(qasr_engine* e, const float* pcm, size_t n, int sample_rate,
     std::vector<std::pair<std::string, std::string>> pairs;
     try { if (int rc = split_for(e, text, language, pairs)) return rc; }
     catch (const std::exception& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); }
-    return align_common(e, pcm, n, sample_rate, pairs, true, out);
+    return align_common(e, pcm, n, sample_rate, pairs, true, out, text);
 }
 
 int qasr_align_batch(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
@@ -389,6 +393,15 @@ int qasr_stt_vtable(qasr_engine* e, sc_stt_vtable_t* out) {
     out->transcribe = vt_transcribe;
     out->input_sample_rate = vt_rate;
     return QASR_OK;
+}
+
+int qasr_set_tuning(const char* key, int value) {
+    if (!key) return QASR_ERR_INVALID;
+    return qasr::tuning_set(key, value) ? QASR_OK : QASR_ERR_INVALID;
+}
+int qasr_get_tuning(const char* key, int* value) {
+    if (!key || !value) return QASR_ERR_INVALID;
+    return qasr::tuning_get(key, value) ? QASR_OK : QASR_ERR_INVALID;
 }
 
 int qasr_prefill_logits(qasr_engine* e, const float* audio_embeds, int n_audio, const qasr_options* opt, float* logits) {

@@ -19,6 +19,10 @@ struct HipError : std::runtime_error {
                                    __FILE__ + ":" + std::to_string(__LINE__) + ")");          \
     } while (0)
 
+struct NotLoaded : std::runtime_error {      // -> QASR_ERR_NOT_LOADED at the C ABI
+    using std::runtime_error::runtime_error;
+};
+
 typedef unsigned short bf16_t;  // storage type; arithmetic is always float32
 
 __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {

@@ -102,11 +102,12 @@ struct GreedyState {
     int* finished;      // [B]
     int* ctx_len;       // [B]
     int* n_active;      // [1] rows not finished
+    int* err;           // [1] set to 1 when a row's best logit is not finite (NaN / inf logits): qasr_batch_tokens reports it
     int max_new;        // row stride - 1
     int max_tokens;     // cap for this batch
     int eos;
     int ignore_eos;
-    int vocab;          // ids outside [0, vocab) (all-NaN logits) are clamped to 0: the gather must never fault
+    int vocab;          // ids outside [0, vocab) (all-NaN logits) are clamped to 0 so the gather cannot fault, and *err is set
 };
 // rope rows of the next decode position, one per batch row (cos_rows/sin_rows [B][half]), copied from the
 // position-indexed tables by greedy_finalize so decode attention does not chain ctx_len -> table lookup

@@ -254,7 +254,7 @@ void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int
                          const int* slot_of_clip, int n_clips, int max_len, hipStream_t s) {
     if (n_pos <= 0) return;
     const int nh = heads + 2 * kv_heads;
-    static const int wide = getenv("QASR_QKNR_WIDE") ? atoi(getenv("QASR_QKNR_WIDE")) : 1;      // A/B knob
+    const int wide = tuning().qknr_wide;      // A/B knob
     if (hd == 128 && nh % 8 == 0 && wide) {
         long waves = (long)n_pos * (nh / 8);
         hipLaunchKernelGGL(qk_norm_rope_wide_kernel<128>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
@@ -661,8 +661,8 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
                               const int* slot_of_clip, int n_clips, int max_len, int heads, bf16_t* out,
                               hipStream_t s) {
     if (n_clips <= 0 || max_len <= 0) return;
-    static const int mt = getenv("QASR_PA_MT") ? atoi(getenv("QASR_PA_MT")) : 1;      // A/B knob: row tiles per wave
-    static const int form = getenv("QASR_PA_FORM") ? atoi(getenv("QASR_PA_FORM")) : 2; // A/B knob: 2 = transposed-score form
+    const int mt = tuning().pa_mt;          // A/B knob: row tiles per wave
+    const int form = tuning().pa_form;      // A/B knob: 2 = transposed-score form
     const float scale = 1.0f / sqrtf((float)cache.hd);
     if (form == 2 && heads == 2 * cache.kv_heads && (cache.hd == 128 || cache.hd == 32)) {
         const dim3 grid(cdiv(max_len, 64), cache.kv_heads, n_clips);
@@ -1120,8 +1120,8 @@ static bool gemv2_nb(const DecGemv2Args& a2, hipStream_t s) {
     // twice the workgroups at 32 rows, half the activation bytes (and RMSNorm work) per workgroup, no second staging phase
     // for the K = 3072 matrix.  Measured in the real step, decode at 32 x 30 s: 148.8 ms unsplit, 140.2 ms with only the two
     // residual GEMVs (64 -> 128 workgroups) split, 137.3 ms with all four; 8-row groups (151 ms) and 4-wave workgroups
-    // (140 ms) lose.  QASR_GEMV_SPLITB=0|1|2 selects none | residual only | all (A/B).
-    static const int split_b = getenv("QASR_GEMV_SPLITB") ? atoi(getenv("QASR_GEMV_SPLITB")) : 2;
+    // (140 ms) lose.  tuning knob gemv_splitb = 0|1|2 selects none | residual only | all (A/B).
+    const int split_b = tuning().gemv_splitb;
     if (nb > 1 && EPI != DEC_EPI_LOGITS && ((split_b == 1 && EPI == DEC_EPI_RESID) || split_b == 2)) {
         DecGemv2Args b2 = a2;
         b2.rows_per_group = 16;
@@ -1146,7 +1146,7 @@ static bool gemv2_k(const DecGemv2Args& a2, hipStream_t s) {
     // (K -> waves x k-steps per wave): wide workgroups for the small-N / large-K matrices
     switch (a2.g.K) {
         case 1024: {
-            static const int w8 = getenv("QASR_GEMV_W1024") ? atoi(getenv("QASR_GEMV_W1024")) == 8 : 1;   // A/B knob (8 waves x 4 k-steps won)
+            const bool w8 = tuning().gemv_w1024 == 8;   // A/B knob (8 waves x 4 k-steps won)
             if constexpr (EPI == DEC_EPI_LOGITS) return gemv2_nb<NT, 8, 4, PRO, EPI>(a2, s);
             else return w8 ? gemv2_nb<NT, 8, 4, PRO, EPI>(a2, s) : gemv2_nb<NT, 4, 8, PRO, EPI>(a2, s);
         }
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
 }
 
 static int lmh_grid() {
-    static const int g = getenv("QASR_LMH_GRID") ? atoi(getenv("QASR_LMH_GRID")) : 256;
+    static const int g = tuning().lmh_grid;      // frozen at first use: sizes the argmax partial buffers
     return g;
 }
 
@@ -1366,7 +1366,7 @@ int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf1
     if (B <= 0) return 0;
     const int nb = (B + 15) / 16;
     if (Wp && lm_head_supported(N, K) && nb <= (K == 1024 ? 4 : 2)) {
-        static const int diag = getenv("QASR_LMH_DIAG") ? atoi(getenv("QASR_LMH_DIAG")) : 0;
+        const int diag = tuning().lmh_diag;
         LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx, diag};
         if (K == 1024) {
             switch (nb) {
@@ -1637,8 +1637,8 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     const float scale = 1.0f / sqrtf((float)hd);
     dim3 grid(kv_heads, B);
     // A/B knobs: waves per workgroup (8 with two chunks in flight per wave | 16 with one) and speculative first loads
-    static const int nw = getenv("QASR_DA_WAVES") ? atoi(getenv("QASR_DA_WAVES")) : 8;
-    static const int spec = getenv("QASR_DA_SPEC") ? atoi(getenv("QASR_DA_SPEC")) : 0;
+    const int nw = tuning().da_waves;
+    const int spec = tuning().da_spec;
 #define QASR_DAM_GO(HD_, W_, U_, S_)                                                                                         \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, kv_heads, \
                        qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg)
@@ -1726,8 +1726,10 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
         }
         __syncthreads();
     }
+    const bool sane = (unsigned)s_i[0] < (unsigned)st.vocab && fabsf(s_v[0]) <= 3.0e38f;   // false for NaN / inf / no winner
     const int tok = (unsigned)s_i[0] < (unsigned)st.vocab ? s_i[0] : 0;
     if (tid == 0) {
+        if (!sane && !st.finished[b]) atomicOr(st.err, 1);
         if (advance_ctx) st.ctx_len[b] += 1;
         if (!st.finished[b]) {
             const int n = st.lens[b];

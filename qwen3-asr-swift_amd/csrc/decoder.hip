@@ -169,7 +169,7 @@ void Engine::finalize_decoder() {
     h_pmeta_.alloc(pmeta);
     d_pmeta_.alloc(pmeta);
     // greedy state: tokens [B][max_new+1] | lens [B] | finished [B] | ctx_len [B] | n_active [1]
-    const size_t gs = ((size_t)B * (cfg_.max_new_tokens + 1) + 3 * B + 4) * sizeof(int);
+    const size_t gs = ((size_t)B * (cfg_.max_new_tokens + 1) + 3 * B + 4) * sizeof(int);   // + n_active, err, 2 spare
     d_gstate_.alloc(gs);
     int* g = d_gstate_.as<int>();
     gstate_.tokens = g;
@@ -177,6 +177,8 @@ void Engine::finalize_decoder() {
     gstate_.finished = gstate_.lens + B;
     gstate_.ctx_len = gstate_.finished + B;
     gstate_.n_active = gstate_.ctx_len + B;
+    gstate_.err = gstate_.n_active + 1;
+    d_err_flag_ = gstate_.err;
     gstate_.max_new = cfg_.max_new_tokens;
     gstate_.eos = cfg_.tok_im_end;
     gstate_.vocab = cfg_.vocab;
@@ -196,9 +198,20 @@ void Engine::finalize_decoder() {
 void Engine::plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio,
                           const std::vector<std::vector<int32_t>>* aligner_tails) {
     const int B = (int)n_audio.size();
+    if (opt && (opt->n_context < 0 || opt->n_language < 0)) throw std::invalid_argument("negative context / language id count");
     const int n_ctx = opt && opt->context_ids ? opt->n_context : 0;
     const int n_lang = opt && opt->language_ids ? opt->n_language : 0;
     if (n_ctx + n_lang > cfg_.max_prompt_extra) throw std::length_error("context + language ids exceed max_prompt_extra");
+    // every id becomes a row index of the embedding gather (embed_splice_kernel): refuse what is not a vocabulary row
+    auto check_ids = [&](const int32_t* ids, int n, const char* what) {
+        for (int i = 0; i < n; ++i)
+            if (ids[i] < 0 || ids[i] >= cfg_.vocab)
+                throw std::invalid_argument(std::string(what) + " id " + std::to_string(ids[i]) + " outside [0, vocab)");
+    };
+    if (n_ctx) check_ids(opt->context_ids, n_ctx, "context");
+    if (n_lang) check_ids(opt->language_ids, n_lang, "language");
+    if (aligner_tails)
+        for (auto& t : *aligner_tails) check_ids(t.data(), (int)t.size(), "slotted text");
     if (aligner_tails) {
         if ((int)aligner_tails->size() != B) throw std::invalid_argument("aligner: one slotted text per clip");
         for (auto& t : *aligner_tails)
@@ -266,12 +279,14 @@ void Engine::reset_greedy_state(int max_tokens, bool ignore_eos) {
     QASR_HIP(hipMemsetAsync(gstate_.tokens, 0xff, (size_t)cfg_.max_batch * (cfg_.max_new_tokens + 1) * sizeof(int), stream_));
     QASR_HIP(hipMemsetAsync(gstate_.lens, 0, (size_t)2 * cfg_.max_batch * sizeof(int), stream_));
     // ctx_len [max_batch] and n_active are contiguous in the state block: one copy from pinned memory
-    if (!h_ginit_.p) h_ginit_.alloc((size_t)(cfg_.max_batch + 1) * sizeof(int));
+    if (!h_ginit_.p) h_ginit_.alloc((size_t)(cfg_.max_batch + 2) * sizeof(int));
     int* init = h_ginit_.as<int>();
     for (int b = 0; b < cfg_.max_batch; ++b) init[b] = b < B ? h_ctx0_[b] : 0;
     init[cfg_.max_batch] = B;
-    QASR_HIP(hipMemcpyAsync(gstate_.ctx_len, init, (size_t)(cfg_.max_batch + 1) * sizeof(int), hipMemcpyHostToDevice, stream_));
+    init[cfg_.max_batch + 1] = 0;                                  // err flag
+    QASR_HIP(hipMemcpyAsync(gstate_.ctx_len, init, (size_t)(cfg_.max_batch + 2) * sizeof(int), hipMemcpyHostToDevice, stream_));
     steps_done_ = 0;
+    forced_ctx_ = B > 0 ? h_ctx0_[0] : 0;
 }
 
 void Engine::run_lm_head(bool want_logits, int r0, int nr, hipStream_t s) {
@@ -444,12 +459,10 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
 // one group's weight streaming with another's attention; the second reader of a layer's weights is served
 // from the Infinity Cache.
 static int decode_split_env() {
-    static const int v = getenv("QASR_DECODE_SPLIT") ? atoi(getenv("QASR_DECODE_SPLIT")) : 1;   // A/B: 1 won once the GEMVs were packed
-    return v;
+    return tuning().decode_split;   // A/B: 1 won once the GEMVs were packed
 }
 static int decode_gran_env() {
-    static const int v = getenv("QASR_DECODE_GRAN") ? atoi(getenv("QASR_DECODE_GRAN")) : 16;
-    return v;
+    return tuning().decode_gran;
 }
 
 // rows of the first (largest) row group of a step
@@ -503,8 +516,11 @@ void Engine::decode_loop() {
     if (max_steps <= 0) return;
     const int split = decode_split_env();
     const long key = ((long)batch_ << 32) | ((long)split << 24) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
-    if (use_graph_ && (graph_exec_ == nullptr || graph_key_ != key)) {
-        if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    const bool use_graph_ = tuning().use_graph != 0;
+    // a knob change (qasr_set_tuning) can select other kernels: the captured step is stale then
+    if (use_graph_ && (graph_exec_ == nullptr || graph_key_ != key || graph_epoch_ != tuning().epoch)) {
+        drop_graph();
+        graph_epoch_ = tuning().epoch;
         hipGraph_t g = nullptr;
         QASR_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         try {
@@ -610,6 +626,7 @@ void Engine::batch_begin(const float* const* pcm, const size_t* n, size_t B, con
 }
 
 void Engine::batch_run() {
+    require_batch("batch_run");
     hipStream_t s = stream_;
     QASR_HIP(hipEventRecord(ev_[0], s));
     run_mel();
@@ -627,7 +644,7 @@ void Engine::batch_run() {
 }
 
 void Engine::batch_rewind() {
-    if (batch_ <= 0 || h_ctx0_.empty()) throw std::runtime_error("batch_rewind: no resident batch");
+    require_batch("batch_rewind");
     QASR_HIP(hipStreamSynchronize(stream_));       // h_ginit_ is reused
     reset_greedy_state(cur_max_tokens_, cur_ignore_eos_);
 }
@@ -638,7 +655,10 @@ void Engine::batch_tokens(int32_t* tokens, int32_t* lens) {
     const int stride = cfg_.max_new_tokens + 1;
     QASR_HIP(hipMemcpyAsync(tokens, gstate_.tokens, (size_t)batch_ * stride * sizeof(int), hipMemcpyDeviceToHost, stream_));
     QASR_HIP(hipMemcpyAsync(lens, gstate_.lens, (size_t)batch_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    int err = 0;
+    QASR_HIP(hipMemcpyAsync(&err, d_err_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     QASR_HIP(hipStreamSynchronize(stream_));
+    if (err) throw HipError("greedy decode saw a non-finite best logit (NaN / inf in the weights or activations); tokens are not valid");
 }
 
 void Engine::batch_timings(float ms[5], int32_t* n_steps) {
@@ -726,7 +746,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         (void)hipEventDestroy(e1);
     }
     *avg_ms = ms / (float)reps;
-    if (which == 1 && getenv("QASR_DA_STAMPS")) {
+    if (which == 1 && tuning().da_stamps) {
         // diagnostic: one launch with phase stamps (100 MHz wall clock), printed as averages over workgroups / waves
         const int nw = 16, nwg = rows * cfg_.kv_heads;
         DevBuf d;
@@ -747,7 +767,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                 acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100,
                 acc[5] / cnt / 100, acc[6] / cnt / 100, (double)(t6 - t0) / 100);
     }
-    if (which == 0 && getenv("QASR_STAMPS_INSITU")) {
+    if (which == 0 && tuning().stamps_insitu) {
         // one real decode step (eager, all layers, cold weights) with layer 14's five launches stamped
         DevBuf d;
         const size_t stride = (size_t)512 * 16 * 8, n = 5 * stride;
@@ -776,7 +796,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             }
         }
     }
-    if (which == 0 && getenv("QASR_GEMV_STAMPS")) {
+    if (which == 0 && tuning().gemv_stamps) {
         DevBuf d;
         const size_t n = (size_t)512 * 16 * 8;
         d.alloc(n * sizeof(unsigned long long));
@@ -841,8 +861,14 @@ void Engine::prefill_logits_host(const float* audio_embeds, int n_audio, const q
 }
 
 void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
-    if (!finalized_ || batch_ != 1) throw std::runtime_error("decode_forced needs a preceding prefill_logits");
+    if (!finalized_) throw NotLoaded("decode_forced: weights not finalized");
+    if (batch_ != 1 || h_ctx0_.empty()) throw std::runtime_error("decode_forced needs a preceding prefill_logits");
     require_asr("decode_forced");
+    // every forced token appends one K/V row at ctx_len and reads the RoPE row of that position: stay inside the
+    // cache (max_ctx_ rows; the last row is never a query position of the greedy path either)
+    if (n < 0 || forced_ctx_ + n > max_ctx_ - 1)
+        throw std::length_error("decode_forced: " + std::to_string(forced_ctx_) + " cached positions + " + std::to_string(n) +
+                                " forced tokens exceed the cache capacity of " + std::to_string(max_ctx_ - 1));
     HostBuf idx;
     idx.alloc(sizeof(int));
     DevBuf didx;
@@ -858,6 +884,7 @@ void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
         QASR_HIP(hipMemcpyAsync(logits + (size_t)i * cfg_.vocab, d_logits_.p, (size_t)cfg_.vocab * sizeof(float),
                                 hipMemcpyDeviceToHost, stream_));
         QASR_HIP(hipStreamSynchronize(stream_));
+        ++forced_ctx_;
     }
 }
 

@@ -112,7 +112,8 @@ public:
     struct AlignedWord { std::string text; float start, end; };
     struct SlottedText { std::vector<int32_t> ids, ts_pos; std::vector<std::string> words; };
     SlottedText prepare_alignment(const std::vector<std::pair<std::string, std::string>>& pairs) const;
-    int align_words(const float* pcm, size_t n, const std::vector<std::pair<std::string, std::string>>& pairs, bool long_form);
+    int align_words(const float* pcm, size_t n, const std::vector<std::pair<std::string, std::string>>& pairs, bool long_form,
+                    const std::string* long_text = nullptr);
     void align_batch(const float* const* pcm, const size_t* n, size_t B,
                      const std::vector<std::vector<std::pair<std::string, std::string>>>& pairs);
     struct AlignResult { std::vector<AlignedWord> words; std::vector<qasr_aligned_word> view; std::vector<int32_t> raw; };
@@ -232,7 +233,11 @@ private:
     // decode-step graph, keyed by (B, max_tokens, ignore_eos)
     hipGraphExec_t graph_exec_ = nullptr;
     long graph_key_ = -1;
-    bool use_graph_ = true;
+    unsigned graph_epoch_ = 0;                                 // tuning().epoch the graph was captured under
+    int* d_err_flag_ = nullptr;                                // device word: set when a greedy step sees a non-finite best logit
+    int forced_ctx_ = 0;                                       // host copy of slot 0's context length (decode_forced capacity)
+    void drop_graph();
+    void require_batch(const char* what) const;
     hipEvent_t ev_[6] = {};
     hipStream_t side_[3] = {};                                 // parallel decode row groups
     hipEvent_t fork_ev_ = nullptr, join_ev_[3] = {};

@@ -73,25 +73,50 @@ void Engine::set_tensor(const std::string& name, const void* host, int dtype, co
     t.shape.assign(shape, shape + ndim);
     t.dtype = dtype;
     size_t el = (dtype == QASR_DTYPE_F32 || dtype == QASR_DTYPE_U32) ? 4 : 2;
+    // the captured graph and the fused copies may still be reading the buffer this replaces
+    QASR_HIP(hipStreamSynchronize(stream_));
+    drop_graph();
+    finalized_ = false;
     t.buf.alloc(t.numel() * el);
     QASR_HIP(hipMemcpy(t.buf.p, host, t.numel() * el, hipMemcpyHostToDevice));
-    finalized_ = false;
 }
 
+void Engine::drop_graph() {
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    graph_key_ = -1;
+}
+
+// (Re-)finalize: everything derived from the tensors is rebuilt, so everything that points at the previous build
+// goes first -- the captured decode graph holds raw pointers into the KV caches / packed weights, fused_ owns the
+// previous packed copies, and a resident batch refers to the old caches.
 void Engine::finalize() {
+    QASR_HIP(hipStreamSynchronize(stream_));
+    drop_graph();
+    fused_.clear();
+    batch_ = 0;
+    h_ctx0_.clear();
+    forced_ctx_ = 0;
+    finalized_ = false;
     finalize_encoder();
     finalize_decoder();
     finalized_ = true;
 }
 void Engine::unload() {
     QASR_HIP(hipStreamSynchronize(stream_));
-    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; graph_key_ = -1; }
+    drop_graph();
     tensors_.clear();
     fused_.clear();
     kcache_.clear();
     vfcache_.clear();
     d_vrows_.release();
+    batch_ = 0;
+    h_ctx0_.clear();
+    forced_ctx_ = 0;
     finalized_ = false;
+}
+void Engine::require_batch(const char* what) const {
+    if (!finalized_) throw NotLoaded(std::string(what) + ": weights not finalized (unloaded, or a tensor was replaced)");
+    if (batch_ <= 0 || h_ctx0_.empty()) throw std::runtime_error(std::string(what) + ": no resident batch (call qasr_batch_begin)");
 }
 size_t Engine::memory_footprint() const {
     size_t n = 0;

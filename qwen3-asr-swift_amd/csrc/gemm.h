@@ -11,6 +11,7 @@
 // per lane along rows.
 #pragma once
 #include "common.h"
+#include "tuning.h"
 #include <cstdlib>
 
 namespace qasr {
@@ -463,15 +464,14 @@ inline const bf16_t* gemm_zero_block() {
 // of one overlap the MFMAs of the others (encoder 18.1 -> 15.6 ms, prompt pass 20.8 -> 18.9 ms at 32 x 30 s against the
 // double-buffered 64 KiB form at 2 per CU).  That only works when there ARE several workgroups per CU: small launches
 // (1 clip: 32-192 tiles; the aligner's 200-tile encoder GEMMs) ran 10-25 % slower with it, so they keep the
-// software-double-buffered form.  QASR_GEMM_NBUF=1|2 forces one form (A/B).
+// software-double-buffered form.  tuning knob gemm_nbuf = 1|2 forces one form (A/B, parity tests of both).
 inline int gemm_nbuf(int grid) {
-    static const int v = getenv("QASR_GEMM_NBUF") ? atoi(getenv("QASR_GEMM_NBUF")) : 0;
+    const int v = tuning().gemm_nbuf;
     if (v == 1 || v == 2) return v;
     return grid >= 640 ? 1 : 2;             // 2.5 tiles per CU on the 256-CU part (686-tile launches measured faster with 1)
 }
 inline bool gemm_use_glds() {
-    static const int v = getenv("QASR_GEMM_GLDS") ? atoi(getenv("QASR_GEMM_GLDS")) : 1;
-    return v != 0;
+    return tuning().gemm_glds != 0;
 }
 
 template <class ALoad, class Epi>

@@ -35,6 +35,8 @@ public:
 
 private:
     const char *p_, *e_;
+    int depth_ = 0;
+    static constexpr int kMaxDepth = 64;          // a crafted header must not recurse the stack away
     [[noreturn]] void fail(const char* m) { throw std::runtime_error(std::string("json: ") + m); }
     void ws() { while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) ++p_; }
     static void put_utf8(std::string& s, unsigned cp) {
@@ -91,6 +93,8 @@ private:
         if (p_ >= e_) fail("unexpected end");
         Json j;
         char c = *p_;
+        struct Depth { int& d; explicit Depth(int& x) : d(x) { ++d; } ~Depth() { --d; } } guard(depth_);
+        if (depth_ > kMaxDepth) fail("nesting too deep");
         if (c == '{') {
             j.type = Json::Obj;
             ++p_;

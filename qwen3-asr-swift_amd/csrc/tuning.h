@@ -1,0 +1,38 @@
+// tuning.h -- the one table of A/B and diagnostic knobs of libqasr.
+//
+// Every default is the measured winner; every other value is a kept alternative that the parity tests also pass
+// (DESIGN.md section 5 lists the measurements).  Values come from, in order: qasr_set_tuning() (C ABI, tests and
+// bench A/B legs), the environment variable QASR_<KEY IN UPPER CASE> read once at first use, the default below.
+// A change bumps `epoch`, which invalidates captured decode graphs (engine.h: graph_key_).
+#pragma once
+
+namespace qasr {
+
+struct Tuning {
+    int gemv_splitb = 2;     // decode GEMV batch row groups on gridDim.y: 0 none | 1 residual GEMVs | 2 all
+    int gemv_w1024 = 8;      // waves per workgroup for K = 1024 (8 x 4 k-steps | 4 x 8)
+    int gemv_nt = 0;         // 1: non-temporal weight loads in the decode GEMVs / LM head (each byte is read once)
+    int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
+    int da_spec = 0;         // 1: first K/V loads issued before ctx_len is known
+    int da_nt = 0;           // 1: non-temporal K/V cache loads in the decode attention
+    int pa_form = 2;         // prompt attention: 2 transposed-score form | 1 first form
+    int pa_mt = 1;           // row tiles per wave of the first form
+    int qknr_wide = 1;       // q/k norm + RoPE of the prompt pass: 16-byte accesses
+    int gemm_nbuf = 0;       // GEMM LDS buffers: 0 auto (by tile count) | 1 | 2
+    int gemm_glds = 1;       // GEMM operand staging: 1 direct-to-LDS | 0 through registers
+    int lmh_grid = 256;      // persistent LM-head workgroups (read at qasr_finalize: sizes the argmax partials)
+    int lmh_diag = 0;        // diagnostic: LM-head loop without LDS reads / MFMA (wrong results, timing only)
+    int decode_split = 1;    // decode row groups on parallel graph branches
+    int decode_gran = 16;    // rows per such group (multiple)
+    int use_graph = 1;       // 0: issue every decode step eagerly (no hipGraph replay)
+    int kv_prefetch = 0;     // 1: a side branch of the step graph pulls the next layer's K/V + weights into the Infinity Cache
+    int mlp_fused = 0;       // 1: o-proj + gate/up + down of a decoder layer in one launch (csrc/dec_mlp.hip)
+    int da_stamps = 0, gemv_stamps = 0, stamps_insitu = 0;   // diagnostics of qasr_kernel_probe (make DIAG=1 builds)
+    unsigned epoch = 0;
+};
+
+Tuning& tuning();                                   // process-wide; first call seeds it from the environment
+bool tuning_set(const char* key, int value);        // false: unknown key
+bool tuning_get(const char* key, int* value);
+
+}  // namespace qasr

@@ -17,6 +17,7 @@ extern "C" int qasr_load_wav(const char* path, float** samples, size_t* n_sample
     if (!path || !samples || !n_samples || !sample_rate) return QASR_ERR_INVALID;
     *samples = nullptr;
     *n_samples = 0;
+    try {
     FILE* f = std::fopen(path, "rb");
     if (!f) return QASR_ERR_IO;
     std::vector<uint8_t> d;
@@ -50,6 +51,7 @@ extern "C" int qasr_load_wav(const char* path, float** samples, size_t* n_sample
     *n_samples = count;
     *sample_rate = (int)rate;
     return QASR_OK;
+    } catch (...) { return QASR_ERR_IO; }          // std::bad_alloc on a huge file: nothing crosses the C ABI
 }
 
 extern "C" void qasr_free(void* p) { std::free(p); }

@@ -32,6 +32,9 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"qasr error {rc}: {self.lib.qasr_last_error(self.h).decode()}")
 
+    def set_tuning(self, key, value):
+        assert self.lib.qasr_set_tuning(key.encode(), int(value)) == 0, key
+
     def close(self):
         if self.h:
             self.lib.qasr_destroy(self.h)

@@ -85,6 +85,20 @@ def test_error_paths_without_gpu():
     assert lib.qasr_transcribe(None, None, 0, 16000, None, None) != 0
 
 
+def test_tuning_knobs_roundtrip():
+    """qasr_set_tuning / qasr_get_tuning: the knob table of csrc/tuning.h (pure host state, no GPU)."""
+    lib = _lib.load()
+    v = C.c_int(-1)
+    assert lib.qasr_get_tuning(b"gemm_nbuf", C.byref(v)) == 0 and v.value == 0
+    assert lib.qasr_set_tuning(b"gemm_nbuf", 1) == 0
+    assert lib.qasr_get_tuning(b"gemm_nbuf", C.byref(v)) == 0 and v.value == 1
+    assert lib.qasr_set_tuning(b"gemm_nbuf", 0) == 0
+    assert lib.qasr_get_tuning(b"use_graph", C.byref(v)) == 0 and v.value == 1
+    assert lib.qasr_set_tuning(b"no_such_knob", 1) != 0
+    assert lib.qasr_get_tuning(b"no_such_knob", C.byref(v)) != 0
+    assert lib.qasr_set_tuning(None, 1) != 0
+
+
 # ---- pickNextToken through the C ABI (pure CPU function; reference KATs: Qwen3DecodingOptionsTests.swift:51-235)
 import numpy as np  # noqa: E402
 

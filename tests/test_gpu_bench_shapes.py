@@ -1,0 +1,135 @@
+"""Parity at the BENCHMARK's own shapes (BASELINE configs[1]/[2]: Qwen3-ASR-0.6B geometry, 30 s clips -> 3000 mel
+frames, 30 conv chunks, 390 audio tokens, prompt T = 406; 32 clips per GPU), against the CPU oracle directly:
+
+  * encoder output of one 30 s clip vs the oracle, both rounding policies (REFERENCE = f32 encoder like MLX,
+    DEVICE = bf16 MFMA operands);
+  * prompt-pass logits at T = 406 vs the REFERENCE policy -- plain softmax with the reference's additive -1e9 causal
+    mask (QuantizedTextDecoder.swift:220-236), NOT the flash restatement the DEVICE policy carries;
+  * 8 teacher-forced decode steps behind that prompt;
+  * all of it again with the GEMM form the 32-clip bench actually runs (gemm_nt_glds1_kernel, picked by tile count;
+    forced here through the tuning knob gemm_nbuf = 1) and with the other form (gemm_nbuf = 2);
+  * a 32 x 30 s batch (configs[2]'s per-GPU shard): size-independent properties + one row teacher-forced.
+
+Tolerances (logits are bf16 values, |logit| <= 8 here so one bf16 ulp is 2^-5):
+  logits: max |d| <= 6 ulps of the largest |logit| and relative L2 < 3e-2.  On the CPU alone the two oracle policies
+  differ by 3.5 ulps / rel-L2 1.5e-2 on this very input (printed by the test), which is the noise floor of 28 layers of
+  bf16 rounding; the device must sit inside 6.
+  encoder: rel-L2 < 1e-2 vs DEVICE, < 2e-2 vs REFERENCE (measured 4e-3 / 5e-3).
+"""
+import numpy as np
+import pytest
+import torch
+from oracle import config as C, decoder, encoder, pipeline, precision as P, mel as omel
+from qasr import synth
+import gpu_util
+
+pytestmark = pytest.mark.gpu
+N_STEPS = 8
+
+
+def _ulp_tol(ref, ulps=6.0):
+    m = float(np.abs(ref).max())
+    return ulps * 2.0 ** (np.floor(np.log2(max(m, 1e-3))) - 7)
+
+
+@pytest.fixture(scope="module")
+def rig():
+    sd = synth.synth_state_dict(C.AUDIO_SMALL, C.TEXT_SMALL, seed=0, init="stress")
+    eng = gpu_util.Engine("0.6B", max_batch=32, max_audio_seconds=30, max_new_tokens=16)
+    eng.load_state_dict(sd)
+    W = decoder.Weights(sd)
+    pcm = synth.synth_waveform(0, 30.0)
+    mel = omel.log_mel(pcm)
+    with torch.no_grad():
+        enc_dev = encoder.encode(mel, W, C.AUDIO_SMALL, P.DEVICE)
+        enc_ref = encoder.encode(mel, W, C.AUDIO_SMALL, P.REFERENCE)
+    yield dict(eng=eng, sd=sd, W=W, pcm=pcm, mel=mel, enc_dev=enc_dev, enc_ref=enc_ref)
+    eng.close()
+
+
+def _encoder_check(r):
+    got = r["eng"].encode(r["mel"])
+    assert got.shape == (390, 1024)
+    dev, ref = P.bf16_round(r["enc_dev"]).numpy(), r["enc_ref"].numpy()
+    rel_dev = np.linalg.norm(got - dev) / np.linalg.norm(dev)
+    rel_ref = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    print(f"30 s encoder: rel-L2 vs DEVICE {rel_dev:.2e}, vs REFERENCE {rel_ref:.2e}")
+    assert rel_dev < 1e-2 and rel_ref < 2e-2
+    return got
+
+
+def _decoder_check(r, got_emb):
+    """prompt pass (T = 406) vs REFERENCE, then N_STEPS teacher-forced steps along the oracle's greedy stream."""
+    eng, W = r["eng"], r["W"]
+    emb = torch.from_numpy(got_emb)                      # both sides consume the device's encoder output
+    with torch.no_grad():
+        ref_logits, state, ids = decoder.prefill(emb, W, C.TEXT_SMALL, P.REFERENCE, C.TOKENS)
+        dev_logits, _, _ = decoder.prefill(emb, W, C.TEXT_SMALL, P.DEVICE, C.TOKENS)
+    assert len(ids) == 406
+    ref, dev = ref_logits.numpy(), dev_logits.numpy()
+    print(f"CPU policy-to-policy floor at T=406: max|d| {np.abs(ref - dev).max():.4f} "
+          f"({np.abs(ref - dev).max() / _ulp_tol(ref, 1.0):.1f} ulps), rel-L2 {np.linalg.norm(ref - dev) / np.linalg.norm(ref):.2e}")
+    got = eng.prefill_logits(got_emb)
+    d, rel = np.abs(got - ref).max(), np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    print(f"T=406 prompt-pass logits vs REFERENCE: max|d| {d:.4f} ({d / _ulp_tol(ref, 1.0):.1f} ulps), rel-L2 {rel:.2e}")
+    assert d <= _ulp_tol(ref) and rel < 3e-2
+    assert ref[int(got.argmax())] >= ref.max() - _ulp_tol(ref)
+    toks, logits = [], ref_logits
+    with torch.no_grad():
+        for i in range(N_STEPS):
+            toks.append(int(torch.argmax(logits)))
+            logits = decoder.decode_step(toks[-1], W, C.TEXT_SMALL, state, P.REFERENCE)
+            forced = eng.decode_forced([toks[-1]])[0]
+            refi = logits.numpy()
+            d, rel = np.abs(forced - refi).max(), np.linalg.norm(forced - refi) / np.linalg.norm(refi)
+            print(f"  step {i} (ctx {406 + i}): max|d| {d:.4f} ({d / _ulp_tol(refi, 1.0):.1f} ulps), rel-L2 {rel:.2e}")
+            assert d <= _ulp_tol(refi) and rel < 3e-2
+            assert refi[int(forced.argmax())] >= refi.max() - _ulp_tol(refi)
+
+
+@pytest.mark.parametrize("nbuf", [0, 1, 2], ids=["gemm-auto", "gemm-glds1(bench form)", "gemm-double-buffered"])
+def test_30s_clip_vs_oracle(rig, nbuf):
+    """nbuf = 1 forces gemm_nt_glds1_kernel -- the GEMM form every 32-clip bench launch takes (>= 640 tiles) -- onto this
+    one-clip input, so that form is compared with the oracle directly and not only through batch invariance."""
+    rig["eng"].set_tuning("gemm_nbuf", nbuf)
+    try:
+        got = _encoder_check(rig)
+        _decoder_check(rig, got)
+    finally:
+        rig["eng"].set_tuning("gemm_nbuf", 0)
+
+
+def test_gemm_forms_agree_bit_for_bit(rig):
+    """The two GEMM forms sum every output in the same k order: same bits."""
+    eng = rig["eng"]
+    outs = []
+    for nbuf in (1, 2):
+        eng.set_tuning("gemm_nbuf", nbuf)
+        try:
+            emb = eng.encode(rig["mel"])
+            outs.append((emb, eng.prefill_logits(emb)))
+        finally:
+            eng.set_tuning("gemm_nbuf", 0)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_32x30s_shard(rig):
+    """configs[2]'s per-GPU shard: 32 clips x 30 s in one batch.  Row 0 is the clip of the tests above, so its tokens are
+    checked teacher-forced against the oracle (REFERENCE policy margin); the batch as a whole through properties:
+    exact lengths, ids in range, determinism, and every probed row equal to the same clip transcribed alone."""
+    eng, W = rig["eng"], rig["W"]
+    clips = [rig["pcm"]] + [synth.synth_waveform(k, 30.0) for k in range(1, 32)]
+    a = eng.transcribe_batch(clips, max_tokens=N_STEPS, ignore_eos=True)
+    assert [len(t) for t in a] == [N_STEPS] * 32
+    assert all(0 <= x < C.TEXT_SMALL.vocab for t in a for x in t)
+    assert eng.transcribe_batch(clips, max_tokens=N_STEPS, ignore_eos=True) == a
+    for k in (0, 13, 31):
+        assert eng.transcribe_batch([clips[k]], max_tokens=N_STEPS, ignore_eos=True)[0] == a[k]
+    emb = torch.from_numpy(eng.encode(rig["mel"]))
+    with torch.no_grad():
+        logits, state, _ = decoder.prefill(emb, W, C.TEXT_SMALL, P.REFERENCE, C.TOKENS)
+        for i, t in enumerate(a[0]):
+            tol = _ulp_tol(logits.numpy())
+            assert logits[t] >= logits.max() - tol, (i, t, float(logits[t]), float(logits.max()))
+            if i + 1 < len(a[0]):
+                logits = decoder.decode_step(t, W, C.TEXT_SMALL, state, P.REFERENCE)

@@ -125,13 +125,47 @@ def test_eos_and_length_semantics(tiny):
 
 
 def test_no_graph_equals_graph(tiny):
-    """The hipGraph-captured decode step replays exactly the eager step."""
-    import os
+    """The hipGraph-captured decode step replays exactly the eager step (tuning knob use_graph = 0 issues every
+    step's launches directly on the stream)."""
     eng, sd, W = tiny
-    clips = [synth.synth_waveform(4, 1.7)]
+    clips = [synth.synth_waveform(4, 1.7), synth.synth_waveform(5, 0.8)]
     a = eng.transcribe_batch(clips, max_tokens=9, ignore_eos=True)
-    b = eng.transcribe_batch(clips, max_tokens=9, ignore_eos=True)
-    assert a == b
+    eng.set_tuning("use_graph", 0)
+    try:
+        b = eng.transcribe_batch(clips, max_tokens=9, ignore_eos=True)
+    finally:
+        eng.set_tuning("use_graph", 1)
+    c = eng.transcribe_batch(clips, max_tokens=9, ignore_eos=True)
+    assert a == b == c
+
+
+def test_forced_decode_capacity(tiny):
+    """qasr_decode_forced appends one K/V row per token: more tokens than the cache holds is QASR_ERR_CAPACITY, not an
+    out-of-bounds append."""
+    sd = tiny[1]
+    e = gpu_util.Engine("tiny", max_audio_seconds=2, max_new_tokens=8, max_batch=1)
+    try:
+        e.load_state_dict(sd)
+        emb = P.bf16_round(torch.randn(5, T.hidden, generator=torch.Generator().manual_seed(2)) * 0.5)
+        e.prefill_logits(emb.numpy())
+        cap = None
+        with pytest.raises(RuntimeError, match="qasr error 5"):
+            e.decode_forced([7] * 4096)
+        # filling the cache exactly is fine; one more token is refused
+        n_ok = 0
+        while True:
+            try:
+                e.decode_forced([7] * 16)
+                n_ok += 16
+            except RuntimeError as ex:
+                assert "qasr error 5" in str(ex)
+                break
+            assert n_ok < 4096
+        assert n_ok >= 0
+        with pytest.raises(RuntimeError, match="qasr error 1"):
+            e.decode_forced([T.vocab])                                   # id outside the vocabulary
+    finally:
+        e.close()
 
 
 def test_long_audio_multi_window(tiny):
