@@ -130,7 +130,9 @@ void Engine::alloc_encoder_workspace() {
     d_c1_.alloc((size_t)max_chunks_ * H1_ * W1_ * C * sizeof(bf16_t));
     d_c2_.alloc((size_t)max_chunks_ * H2_ * W2_ * C * sizeof(bf16_t));
     d_c3_.alloc((size_t)max_chunks_ * H3_ * W3_ * C * sizeof(bf16_t));
-    d_encx_.alloc((size_t)max_tokens_ * D * sizeof(float));
+    // f32 residual stream; also the f32 staging area of the stage entry points (encode_host widens [tokens, enc_out_dim]
+    // into it, prefill_logits_host stages [tokens, hidden]), so it is sized for the wider of the two
+    d_encx_.alloc((size_t)max_tokens_ * std::max(D, cfg_.enc_out_dim) * sizeof(float));
     d_ench_.alloc((size_t)max_tokens_ * D * sizeof(bf16_t));
     d_encqkv_.alloc((size_t)max_tokens_ * 3 * D * sizeof(bf16_t));
     d_enca_.alloc((size_t)max_tokens_ * D * sizeof(bf16_t));
@@ -265,6 +267,7 @@ void Engine::encode_host(const float* mel, int n_frames, float* out) {
     long n = (long)n_tok_ * cfg_.enc_out_dim;
     // reuse the f32 residual buffer as the widened staging area
     float* stage = d_encx_.as<float>();
+    if ((size_t)n * sizeof(float) > d_encx_.bytes) throw std::length_error("encode: staging too small");
     hipLaunchKernelGGL(widen_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream_, d_audio_.as<bf16_t>(), stage, n);
     QASR_HIP(hipMemcpyAsync(out, stage, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
     QASR_HIP(hipStreamSynchronize(stream_));
