@@ -53,15 +53,6 @@ inline float bf16_to_f32_host(bf16_t b) {
 
 __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
-// 16-byte global load; NT = non-temporal (streaming) cache policy for bytes that are read exactly once per launch
-typedef unsigned int u32x4_native __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ uint4 ld16(const void* p) {
-    const u32x4_native* q = reinterpret_cast<const u32x4_native*>(p);
-    const u32x4_native v = NT ? __builtin_nontemporal_load(q) : *q;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator

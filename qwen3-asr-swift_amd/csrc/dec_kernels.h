@@ -93,21 +93,6 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
                              const float* rope_sin, KVLayout cache, bf16_t* out, hipStream_t s,
                              unsigned long long* dbg = nullptr);   // dbg: diagnostic phase stamps, null in product launches
 
-// Cache warm-up for the NEXT decoder layer, issued on a side branch of the step graph while the current layer computes
-// (tuning knob kv_prefetch): plain loads of the layer's packed weights and of the live part of its K / V caches, results
-// discarded.  The bytes land in the die-level Infinity Cache (256 MiB; one layer is ~31 MB of weights + ~2 x 30 MB of
-// K/V at 32 x 30 s), so the consuming kernels -- each bound by how long its LAST byte takes to arrive -- are served on
-// die.  Changes no result.
-struct PrefetchArgs {
-    const void* seg[4];      // weight images (fragment-major copies), may be null
-    long seg_bytes[4];
-    const bf16_t* k;         // K cache of the layer [slot][kv_head][max_ctx][hd]
-    const bf16_t* vf;        // V cache, fragment-major, same extents
-    const int* ctx_len;      // [B]
-    int B, kv_heads, max_ctx, hd;
-};
-void cache_prefetch_launch(const PrefetchArgs& a, hipStream_t s);
-
 // Greedy bookkeeping after the LM head (Qwen3ASR.swift:336-388): argmax over the per-block partials
 // (lowest index wins ties, like MLX argMax), append the token unless the row is finished, mark EOS /
 // length-cap, advance ctx_len (decode steps), and gather the next input embedding.

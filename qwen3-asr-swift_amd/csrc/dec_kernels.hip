@@ -2,7 +2,6 @@
 #include "dec_kernels.h"
 #include <cstdlib>
 #include <cstdio>
-#include <type_traits>
 
 namespace qasr {
 
@@ -869,12 +868,9 @@ struct DecGemv2Args {
     unsigned long long* dbg;   // diagnostic phase stamps (see decode_gemv_stamps), null in product launches
     int row_groups;            // > 1: gridDim.y groups of rows_per_group batch rows (see gemv2_nb)
     int rows_per_group;
-    int nt;                    // 1: non-temporal weight loads (tuning knob gemv_nt)
 };
 
-// NTL: non-temporal weight loads.  A compile-time parameter on purpose: as a run-time branch around two copies of the
-// load block, LLVM merges the copies and drops the hint (no `nt` in the ISA).
-template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool NTL>
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     DecGemvArgs a = a2.g;
@@ -935,7 +931,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
         // instruction reads 1 KiB contiguous (see pack_mfma_a_kernel)
         const bf16_t* wp = a.Wp + ((long)(n0 / 16 + t) * (K / 32)) * 512 + lane * 8;
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) w[t][i] = ld16<NTL>(wp + (long)(wave + WAVES * i) * 512);
+        for (int i = 0; i < KSW; ++i) w[t][i] = *reinterpret_cast<const uint4*>(wp + (long)(wave + WAVES * i) * 512);
     }
     uint2 rsd[NT][NB];
     if constexpr (EPI == DEC_EPI_RESID) {
@@ -1106,16 +1102,13 @@ static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
     if constexpr (lds > 156 * 1024) {
         return false;
     } else {
-        auto go = [&](auto kern) {
-            static bool attr_set = false;          // one flag per instantiation of this generic lambda
-            if (!attr_set) {
-                QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), a2.row_groups > 1 ? a2.row_groups : 1), dim3(WAVES * 64), lds, s, a2);
-        };
-        if (a2.nt) go(decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, true>);
-        else go(decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, false>);
+        auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), a2.row_groups > 1 ? a2.row_groups : 1), dim3(WAVES * 64), lds, s, a2);
         return true;
     }
 }
@@ -1173,7 +1166,7 @@ int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* nor
                              hipStream_t s) {
     if (a.B <= 0) return 0;
     const int nt = dec_nt(epi, a.N);
-    DecGemv2Args a2{a, norm_w, eps, g_gemv_dbg, 1, 16, tuning().gemv_nt};
+    DecGemv2Args a2{a, norm_w, eps, g_gemv_dbg, 1, 16};
     bool ok = false;
     if (a.Wp && a.N % (16 * nt) == 0 && a.B <= 64) {
         if (norm_w) {
@@ -1213,10 +1206,9 @@ struct LmHeadArgs {
     float* part_val;        // [B][gridDim.x]
     int* part_idx;
     int diag;               // 1: diagnostic build of the loop without LDS reads / MFMA (wrong results, timing only)
-    int nt;                 // 1: non-temporal weight loads
 };
 
-template <int K, int NB, bool NTL>
+template <int K, int NB>
 __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int KCH = K / 8, XSTRIDE = 2 * K + 16, NC = K / (32 * LMH_CH);   // chunks per tile
@@ -1233,7 +1225,7 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
         const int tile = gw + (item / NC) * total_waves, ch = item % NC;
         const bf16_t* wp = a.W + ((long)tile * (K / 32) + ch * LMH_CH) * 512 + lane * 8;   // packed, see pack_mfma_a_kernel
 #pragma unroll
-        for (int i = 0; i < LMH_CH; ++i) w[i] = ld16<NTL>(wp + i * 512);
+        for (int i = 0; i < LMH_CH; ++i) w[i] = *reinterpret_cast<const uint4*>(wp + i * 512);
     };
     if (nitems > 0) issue(wa, 0);
     // ---- stage + RMSNorm the batch rows, 16 rows per pass (row on 32 adjacent lanes) --------------------
@@ -1356,15 +1348,13 @@ static int lmh_grid() {
 template <int K, int NB>
 static void lm_head_go(const LmHeadArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)NB * 16 * (2 * K + 16);
-    auto go = [&](auto kern) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(lmh_grid()), dim3(LMH_WAVES * 64), lds, s, a);
-    };
-    if (a.nt) go(lm_head_kernel<K, NB, true>); else go(lm_head_kernel<K, NB, false>);
+    auto kern = lm_head_kernel<K, NB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(lmh_grid()), dim3(LMH_WAVES * 64), lds, s, a);
 }
 
 bool lm_head_supported(int N, int K) { return (K == 1024 || K == 2048) && N % 16 == 0 && N / 16 >= 512 * LMH_WAVES; }
@@ -1377,7 +1367,7 @@ int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf1
     const int nb = (B + 15) / 16;
     if (Wp && lm_head_supported(N, K) && nb <= (K == 1024 ? 4 : 2)) {
         const int diag = tuning().lmh_diag;
-        LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx, diag, tuning().gemv_nt};
+        LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx, diag};
         if (K == 1024) {
             switch (nb) {
                 case 1: lm_head_go<1024, 1>(a, s); break;
@@ -1417,7 +1407,7 @@ __device__ __forceinline__ long vfrag_index(int key, int d) {
     return (((long)kb * DT + (d >> 4)) * 64 + (d & 15) + 16 * g) * 8 + half * 4 + j;
 }
 
-template <int HD, int WAVES, int UNR, bool SPEC, bool NTL>
+template <int HD, int WAVES, int UNR, bool SPEC>
 __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     const bf16_t* __restrict__ qkv, const int* __restrict__ ctx_len, int heads, int kv_heads,
     const bf16_t* __restrict__ qn_w, const bf16_t* __restrict__ kn_w, float eps, const float* __restrict__ rope_cos,
@@ -1452,10 +1442,10 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
-                    kreg[u][h * KS + ks] = ld16<NTL>(kr + (long)h * 16 * HD + ks * 32);
+                    kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                vreg[u][dt] = ld16<NTL>(vfb + ((long)ch * DT + dt) * 512);
+                vreg[u][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch * DT + dt) * 512);
         }
     };
     int pos;
@@ -1650,14 +1640,8 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     const int nw = tuning().da_waves;
     const int spec = tuning().da_spec;
 #define QASR_DAM_GO(HD_, W_, U_, S_)                                                                                         \
-    do {                                                                                                                         \
-        if (tuning().da_nt)                                                                                                      \
-            hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_, true>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len,   \
-                               heads, kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg);                    \
-        else                                                                                                                     \
-            hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_, false>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len,  \
-                               heads, kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg);                    \
-    } while (0)
+    hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, kv_heads, \
+                       qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg)
     if (hd == 128) {
         if (nw == 16 && spec) QASR_DAM_GO(128, 16, 1, true);
         else if (nw == 16) QASR_DAM_GO(128, 16, 1, false);
@@ -1668,50 +1652,6 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     } else
         throw std::invalid_argument("decode attention: unsupported head_dim");
 #undef QASR_DAM_GO
-}
-
-// ------------------------------------------------------------------------------------------------
-// Cache warm-up (see PrefetchArgs).  Workgroups [0, B * kv_heads) walk one (slot, kv head) block of K and V up to the
-// row's context length, the remaining PF_WG_W workgroups stride over the weight images; every thread keeps four 16-byte
-// loads in flight and throws the data away.
-// ------------------------------------------------------------------------------------------------
-constexpr int PF_WG_W = 128;
-
-__device__ __forceinline__ void pf_touch(const char* p, long bytes, int rank, int nranks) {
-    // 4 KiB per workgroup-iteration and load slot; `rank` / `nranks` = this workgroup among those sharing the segment
-    const long step = (long)nranks * 256 * 16 * 4;
-    for (long off = ((long)rank * 256 + threadIdx.x) * 16; off < bytes; off += step) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long o = off + (long)u * nranks * 256 * 16;
-            v[u] = o < bytes ? *reinterpret_cast<const uint4*>(p + o) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(v[u].x), "v"(v[u].y), "v"(v[u].z), "v"(v[u].w));   // keeps the loads, costs nothing
-    }
-}
-
-__global__ __launch_bounds__(256) void cache_prefetch_kernel(PrefetchArgs a) {
-    const int nkv = a.B * a.kv_heads;
-    if ((int)blockIdx.x < nkv) {
-        const int b = blockIdx.x / a.kv_heads;
-        const long rows = ((long)(a.ctx_len[b] + 31) >> 5) << 5;
-        const long off = (long)blockIdx.x * a.max_ctx * a.hd;                      // KVLayout::off(b, kvh, 0)
-        const long bytes = (rows < a.max_ctx ? rows : a.max_ctx) * a.hd * 2;
-        pf_touch(reinterpret_cast<const char*>(a.k + off), bytes, 0, 1);
-        pf_touch(reinterpret_cast<const char*>(a.vf + off), bytes, 0, 1);
-    } else {
-        const int rank = blockIdx.x - nkv;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (a.seg[i]) pf_touch(reinterpret_cast<const char*>(a.seg[i]), a.seg_bytes[i], rank, PF_WG_W);
-    }
-}
-
-void cache_prefetch_launch(const PrefetchArgs& a, hipStream_t s) {
-    if (a.B <= 0) return;
-    hipLaunchKernelGGL(cache_prefetch_kernel, dim3(a.B * a.kv_heads + PF_WG_W), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

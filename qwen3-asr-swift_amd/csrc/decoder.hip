@@ -421,27 +421,8 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     bf16_t* at = d_dattn_.as<bf16_t>() + (size_t)r0 * nq;
     bf16_t* act = d_dact_.as<bf16_t>() + (size_t)r0 * I;
     const GreedyState gs = greedy_rows(r0);
-    // kv_prefetch: while layer l runs on `s`, a side branch warms the Infinity Cache with layer l + 1's weights and K/V
-    const bool prefetch = tuning().kv_prefetch != 0 && with_head && r0 == 0 && s == stream_;
-    if (prefetch && layer_ev_.size() < (size_t)cfg_.dec_layers) {
-        layer_ev_.resize(cfg_.dec_layers, nullptr);
-        for (auto& e : layer_ev_) if (!e) QASR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
-        if (prefetch && l + 1 < cfg_.dec_layers) {
-            const DecLayerW& N = decw_.layers[l + 1];
-            PrefetchArgs pa{};
-            pa.seg[0] = N.wqkv_p; pa.seg_bytes[0] = (long)nh * hd * H * 2;
-            pa.seg[1] = N.wo_p; pa.seg_bytes[1] = (long)H * nq * 2;
-            pa.seg[2] = N.wgu_p; pa.seg_bytes[2] = (long)2 * I * H * 2;
-            pa.seg[3] = N.wdown_p; pa.seg_bytes[3] = (long)H * I * 2;
-            pa.k = kcache_[l + 1]->as<bf16_t>(); pa.vf = vfcache_[l + 1]->as<bf16_t>();
-            pa.ctx_len = gs.ctx_len; pa.B = nr; pa.kv_heads = cfg_.kv_heads; pa.max_ctx = max_ctx_; pa.hd = hd;
-            QASR_HIP(hipEventRecord(layer_ev_[l], s));
-            QASR_HIP(hipStreamWaitEvent(side_[0], layer_ev_[l], 0));
-            cache_prefetch_launch(pa, side_[0]);
-        }
         KVLayout kv{kcache_[l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
         kv.k += kv.off(r0, 0, 0);
         kv.vf += kv.off(r0, 0, 0);
@@ -465,10 +446,6 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         decode_gemv_set_debug(dbg ? dbg + 3 * dbg_stride : nullptr);
         decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
         decode_gemv_set_debug(nullptr);
-    }
-    if (prefetch) {                                               // the side branch rejoins before the head
-        QASR_HIP(hipEventRecord(join_ev_[0], side_[0]));
-        QASR_HIP(hipStreamWaitEvent(s, join_ev_[0], 0));
     }
     if (!with_head) return;
     run_lm_head(want_logits, r0, nr, s);

@@ -241,7 +241,6 @@ private:
     hipEvent_t ev_[6] = {};
     hipStream_t side_[3] = {};                                 // parallel decode row groups
     hipEvent_t fork_ev_ = nullptr, join_ev_[3] = {};
-    std::vector<hipEvent_t> layer_ev_;                         // kv_prefetch: start-of-layer marks on the main branch
     std::vector<int> h_ctx0_;
     HostBuf h_ginit_;                                          // pinned: ctx_len init [max_batch] | n_active
 

@@ -60,7 +60,6 @@ Engine::~Engine() {
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     if (fork_ev_) (void)hipEventDestroy(fork_ev_);
-    for (auto& e : layer_ev_) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 3; ++i) {
         if (join_ev_[i]) (void)hipEventDestroy(join_ev_[i]);
         if (side_[i]) (void)hipStreamDestroy(side_[i]);

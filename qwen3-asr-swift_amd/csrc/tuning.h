@@ -11,10 +11,8 @@ namespace qasr {
 struct Tuning {
     int gemv_splitb = 2;     // decode GEMV batch row groups on gridDim.y: 0 none | 1 residual GEMVs | 2 all
     int gemv_w1024 = 8;      // waves per workgroup for K = 1024 (8 x 4 k-steps | 4 x 8)
-    int gemv_nt = 0;         // 1: non-temporal weight loads in the decode GEMVs / LM head (each byte is read once)
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
     int da_spec = 0;         // 1: first K/V loads issued before ctx_len is known
-    int da_nt = 0;           // 1: non-temporal K/V cache loads in the decode attention
     int pa_form = 2;         // prompt attention: 2 transposed-score form | 1 first form
     int pa_mt = 1;           // row tiles per wave of the first form
     int qknr_wide = 1;       // q/k norm + RoPE of the prompt pass: 16-byte accesses
@@ -25,8 +23,6 @@ struct Tuning {
     int decode_split = 1;    // decode row groups on parallel graph branches
     int decode_gran = 16;    // rows per such group (multiple)
     int use_graph = 1;       // 0: issue every decode step eagerly (no hipGraph replay)
-    int kv_prefetch = 0;     // 1: a side branch of the step graph pulls the next layer's K/V + weights into the Infinity Cache
-    int mlp_fused = 0;       // 1: o-proj + gate/up + down of a decoder layer in one launch (csrc/dec_mlp.hip)
     int da_stamps = 0, gemv_stamps = 0, stamps_insitu = 0;   // diagnostics of qasr_kernel_probe (make DIAG=1 builds)
     unsigned epoch = 0;
 };
