@@ -23,10 +23,15 @@ import numpy as np
 import torch
 from .config import TextDecoderConfig, TokenIds, TOKENS
 from . import precision as P
+from . import quant as Q
 
 
 class Weights:
-    """State dict wrapper with cached float32 views (weights are stored bf16/f32 tensors)."""
+    """State dict wrapper with cached float32 views (weights are stored bf16/f32 tensors).
+
+    A quantised checkpoint (QuantizedTextModel, QuantizedTextDecoder.swift:178-199) holds MLX triplets for every decoder
+    Linear and the tied embedding: `X.weight` uint32, `X.scales`, `X.biases`; `linear` / `embed_rows` then follow
+    oracle/quant.py (qmv for one row of x, qmm_t for the prompt pass, `dequantized` for the gather)."""
 
     def __init__(self, sd):
         self.sd = sd
@@ -38,6 +43,40 @@ class Weights:
             t = self.sd[key].to(torch.float32)
             self._f32[key] = t
         return t
+
+    def quantized(self, stem):
+        return (stem + ".scales") in self.sd
+
+    def _triplet(self, stem):
+        wq = np.asarray(self.sd[stem + ".weight"]).view(np.uint32)
+        s = np.asarray(torch.as_tensor(self.sd[stem + ".scales"]).to(torch.float32))
+        b = np.asarray(torch.as_tensor(self.sd[stem + ".biases"]).to(torch.float32))
+        bits = 32 * wq.shape[1] // (s.shape[1] * Q.GROUP)
+        return wq, s, b, bits
+
+    def _dequant(self, stem, rounded):
+        key = (stem, rounded)
+        t = self._f32.get(key)
+        if t is None:
+            wq, s, b, bits = self._triplet(stem)
+            t = Q.dequantized(wq, s, b, bits) if rounded else Q.dequantize_f32(wq, s, b, bits)
+            self._f32[key] = t
+        return t
+
+    def linear(self, x, stem):
+        """x [rows, in] @ W^T (no bias, not yet rounded to the activation dtype)."""
+        if not self.quantized(stem):
+            return x @ self(stem + ".weight").T
+        return x @ self._dequant(stem, rounded=x.shape[0] > Q.QMV_MAX_ROWS).T
+
+    def embed_rows(self, ids):
+        idx = torch.as_tensor(ids, dtype=torch.long)
+        stem = "model.embed_tokens"
+        if not self.quantized(stem):
+            return self(stem + ".weight")[idx]
+        wq, s, b, bits = self._triplet(stem)
+        i = idx.numpy()
+        return Q.dequantized(wq[i], s[i], b[i], bits)
 
 
 def rms_norm(x, w, eps, pol: P.Policy):
@@ -110,9 +149,9 @@ def forward(embeds, W: Weights, cfg: TextDecoderConfig, state: DecoderState, pol
     for i in range(cfg.layers):
         p = f"model.layers.{i}"
         h = rms_norm(x, W(p + ".input_layernorm.weight"), cfg.rms_eps, pol)
-        q = pol.dec(h @ W(p + ".self_attn.q_proj.weight").T).reshape(T, cfg.heads, cfg.head_dim)
-        k = pol.dec(h @ W(p + ".self_attn.k_proj.weight").T).reshape(T, cfg.kv_heads, cfg.head_dim)
-        v = pol.dec(h @ W(p + ".self_attn.v_proj.weight").T).reshape(T, cfg.kv_heads, cfg.head_dim)
+        q = pol.dec(W.linear(h, p + ".self_attn.q_proj")).reshape(T, cfg.heads, cfg.head_dim)
+        k = pol.dec(W.linear(h, p + ".self_attn.k_proj")).reshape(T, cfg.kv_heads, cfg.head_dim)
+        v = pol.dec(W.linear(h, p + ".self_attn.v_proj")).reshape(T, cfg.kv_heads, cfg.head_dim)
         q = rms_norm(q, W(p + ".self_attn.q_norm.weight"), cfg.rms_eps, pol)
         k = rms_norm(k, W(p + ".self_attn.k_norm.weight"), cfg.rms_eps, pol)
         q = pol.dec(rope(q, pos, cfg.rope_theta))
@@ -139,22 +178,22 @@ def forward(embeds, W: Weights, cfg: TextDecoderConfig, state: DecoderState, pol
                 pr = P.bf16_round(pr)
             av = pr @ vh
         a = pol.dec(av).transpose(0, 1).reshape(T, cfg.heads * cfg.head_dim)
-        x = pol.dec(x + pol.dec(a @ W(p + ".self_attn.o_proj.weight").T))
+        x = pol.dec(x + pol.dec(W.linear(a, p + ".self_attn.o_proj")))
         h = rms_norm(x, W(p + ".post_attention_layernorm.weight"), cfg.rms_eps, pol)
-        g = pol.dec(h @ W(p + ".mlp.gate_proj.weight").T)
-        u = pol.dec(h @ W(p + ".mlp.up_proj.weight").T)
+        g = pol.dec(W.linear(h, p + ".mlp.gate_proj"))
+        u = pol.dec(W.linear(h, p + ".mlp.up_proj"))
         act = pol.dec(pol.dec(g * torch.sigmoid(g)) * u)
-        x = pol.dec(x + pol.dec(act @ W(p + ".mlp.down_proj.weight").T))
+        x = pol.dec(x + pol.dec(W.linear(act, p + ".mlp.down_proj")))
     return rms_norm(x, W("model.norm.weight"), cfg.rms_eps, pol)
 
 
 def embed(ids, W: Weights):
-    return W("model.embed_tokens.weight")[torch.as_tensor(ids, dtype=torch.long)]
+    return W.embed_rows(ids)
 
 
 def lm_head(h_last, W: Weights, pol: P.Policy):
-    """Tied head on one position: [hidden] -> [vocab] logits in the decoder dtype."""
-    return pol.dec(W("model.embed_tokens.weight") @ h_last)
+    """Tied head on one position: [hidden] -> [vocab] logits in the decoder dtype (`asLinear`, one row of x: qmv)."""
+    return pol.dec(W.linear(h_last[None, :], "model.embed_tokens")[0])
 
 
 def argmax_lowest(logits):

@@ -9,6 +9,15 @@
 
 namespace qasr {
 
+// A checkpoint triplet of an MLX affine-quantised [N][K] matrix as uploaded (row-major); see dec_quant.h
+struct QuantRaw {
+    const uint32_t* wq = nullptr;   // [N][K * bits / 32], element i of a row in word i / (32 / bits), LSB first
+    const void* scales = nullptr;   // [N][K / 64]
+    const void* biases = nullptr;
+    int sb_f32 = 0;                 // 0: bf16 elements, 1: f32
+    int N = 0, K = 0, bits = 0;
+};
+
 // ---- shared small kernels -------------------------------------------------------------------
 // y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps)))  over rows of width H (bf16 in / bf16 out)
 void rmsnorm_rows_launch(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps, hipStream_t s);
@@ -116,8 +125,10 @@ struct RopeRows {
     float* cos_rows; float* sin_rows;
     int half;
 };
+// qembed != null: the next-token embedding is `dequantized(row)` of the quantised table (PreQuantizedEmbedding.swift:35-42)
 void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
-                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, RopeRows rr, hipStream_t s);
+                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, RopeRows rr, hipStream_t s,
+                            const QuantRaw* qembed = nullptr);
 
 // ---- epilogues for the prefill GEMMs ----------------------------------------------------------------
 // x_bf16[m][n] = bf16(x + bf16(acc))   (residual add in the decoder dtype)

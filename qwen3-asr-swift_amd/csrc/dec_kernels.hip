@@ -1,5 +1,7 @@
 // dec_kernels.hip -- text-decoder kernels (see dec_kernels.h).
 #include "dec_kernels.h"
+#include "dec_epilogue.h"
+#include "dec_quant.h"
 #include <cstdlib>
 #include <cstdio>
 
@@ -683,80 +685,6 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
                            qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
     else
         throw std::invalid_argument("prefill attention: head_dim must be 32 or 128");
-}
-
-// accumulator layout: acc[t][b][j] = out[batch b*16 + fr][n0 + t*16 + fc*4 + j]
-template <int NT, int NB, int EPI>
-__device__ __forceinline__ void dec_epilogue(const DecGemvArgs& a, f32x4 (&acc)[NT][NB], int n0, int fr, int fc,
-                                             const uint2 (*resid)[NB] = nullptr) {
-    if (EPI == DEC_EPI_BF16 || EPI == DEC_EPI_RESID) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int row = b * 16 + fr;
-                if (row < a.B) {
-                    bf16_t* p = a.out + (long)row * a.N + n0 + t * 16 + fc * 4;
-                    float4 v = make_float4(acc[t][b][0], acc[t][b][1], acc[t][b][2], acc[t][b][3]);
-                    if (EPI == DEC_EPI_RESID) {
-                        float4 r;
-                        if (resid) {      // residual fetched at kernel start (saves a memory round trip)
-                            const uint2 u = resid[t][b];
-                            r = make_float4(bf16_to_f32((bf16_t)(u.x & 0xffff)), bf16_to_f32((bf16_t)(u.x >> 16)),
-                                            bf16_to_f32((bf16_t)(u.y & 0xffff)), bf16_to_f32((bf16_t)(u.y >> 16)));
-                        } else {
-                            r = load_bf16x4(p);
-                        }
-                        v.x = r.x + bf16_round(v.x); v.y = r.y + bf16_round(v.y);
-                        v.z = r.z + bf16_round(v.z); v.w = r.w + bf16_round(v.w);
-                    }
-                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
-                }
-            }
-    } else if (EPI == DEC_EPI_SWIGLU) {
-        // rows come in blocks of 32: 16 gate rows then the 16 matching up rows -> tile pairs (2i, 2i+1)
-#pragma unroll
-        for (int t = 0; t + 1 < NT; t += 2)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int row = b * 16 + fr;
-                if (row < a.B) {
-                    float4 v;
-                    v.x = swiglu_bf16(acc[t][b][0], acc[t + 1][b][0]);
-                    v.y = swiglu_bf16(acc[t][b][1], acc[t + 1][b][1]);
-                    v.z = swiglu_bf16(acc[t][b][2], acc[t + 1][b][2]);
-                    v.w = swiglu_bf16(acc[t][b][3], acc[t + 1][b][3]);
-                    bf16_t* p = a.out + (long)row * (a.N / 2) + (n0 + t * 16) / 2 + fc * 4;
-                    *reinterpret_cast<uint2*>(p) = pack_bf16x4(v);
-                }
-            }
-    } else {   // DEC_EPI_LOGITS: bf16-rounded logits, per-block argmax with lowest-index ties
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int row = b * 16 + fr;
-            float best = -INFINITY;
-            int bidx = 0x7fffffff;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + t * 16 + fc * 4 + j;
-                    const float v = bf16_round(acc[t][b][j]);
-                    if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
-                    if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
-                }
-#pragma unroll
-            for (int ofs = 16; ofs < 64; ofs <<= 1) {
-                float ov = __shfl_xor(best, ofs, 64);
-                int oi = __shfl_xor(bidx, ofs, 64);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            if (fc == 0 && row < a.B) {
-                a.part_val[(long)row * gridDim.x + blockIdx.x] = best;
-                a.part_idx[(long)row * gridDim.x + blockIdx.x] = bidx;
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1697,7 +1625,7 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
                                                               const int* __restrict__ part_idx, int n_parts,
                                                               GreedyState st, int advance_ctx,
                                                               const bf16_t* __restrict__ embed, bf16_t* __restrict__ x, int H,
-                                                              RopeRows rr) {
+                                                              RopeRows rr, QuantRaw qe) {
     __shared__ float s_v[256];
     __shared__ int s_i[256];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1741,16 +1669,21 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
             }
         }
     }
-    const uint4* src = reinterpret_cast<const uint4*>(embed + (long)tok * H);
     uint4* dst = reinterpret_cast<uint4*>(x + (long)b * H);
+    if (qe.wq) {                                     // quantised table: dequantized(row) (PreQuantizedEmbedding.swift:35-42)
+        for (int i = tid; i < H / 8; i += 256) dst[i] = quant_dequant_chunk(qe, tok, i);
+        return;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(embed + (long)tok * H);
     for (int i = tid; i < H / 8; i += 256) dst[i] = src[i];
 }
 
 void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
-                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, RopeRows rr, hipStream_t s) {
+                            int advance_ctx, const bf16_t* embed, bf16_t* x, int H, RopeRows rr, hipStream_t s,
+                            const QuantRaw* qembed) {
     if (B <= 0) return;
     hipLaunchKernelGGL(greedy_finalize_kernel, dim3(B), dim3(256), 0, s, part_val, part_idx, n_parts, st, advance_ctx,
-                       embed, x, H, rr);
+                       embed, x, H, rr, qembed ? *qembed : QuantRaw{});
 }
 
 }  // namespace qasr

@@ -1,0 +1,693 @@
+// dec_quant.hip -- decode-step kernels on MLX affine-quantised weights (see dec_quant.h).
+#include "dec_quant.h"
+#include "dec_epilogue.h"
+#include <cstdio>
+
+namespace qasr {
+
+template <bool F32>
+__device__ __forceinline__ float sb_at(const void* p, long i) {
+    if constexpr (F32) return reinterpret_cast<const float*>(p)[i];
+    else return bf16_to_f32(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// q (integers < 2^bits) -> bf16 MFMA fragment, exactly: v_cvt_f32_ubyteN then a truncating pack (an integer < 256 has at
+// most 8 significant bits, so its f32 image already is a bf16 value).
+// 4 bit: one word = the lane's 8 elements of a k-step (element j in bits [4j, 4j + 4)).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);      // {hi[31:16], lo[31:16]}
+}
+
+template <int B>
+__device__ __forceinline__ float ubyte_f32(unsigned w) { return (float)((w >> (8 * B)) & 0xFFu); }      // v_cvt_f32_ubyteB
+
+__device__ __forceinline__ mfma_bf16x8 frag_q4(unsigned w) {
+    const unsigned ev = w & 0x0F0F0F0Fu, od = (w >> 4) & 0x0F0F0F0Fu;      // bytes: e0 e2 e4 e6 | e1 e3 e5 e7
+    uint4 o;
+    o.x = pack_hi16(ubyte_f32<0>(ev), ubyte_f32<0>(od));
+    o.y = pack_hi16(ubyte_f32<1>(ev), ubyte_f32<1>(od));
+    o.z = pack_hi16(ubyte_f32<2>(ev), ubyte_f32<2>(od));
+    o.w = pack_hi16(ubyte_f32<3>(ev), ubyte_f32<3>(od));
+    return __builtin_bit_cast(mfma_bf16x8, o);
+}
+
+__device__ __forceinline__ mfma_bf16x8 frag_q8(unsigned w0, unsigned w1) {      // w0 = elements 0..3, w1 = 4..7
+    uint4 o;
+    o.x = pack_hi16(ubyte_f32<0>(w0), ubyte_f32<1>(w0));
+    o.y = pack_hi16(ubyte_f32<2>(w0), ubyte_f32<3>(w0));
+    o.z = pack_hi16(ubyte_f32<0>(w1), ubyte_f32<1>(w1));
+    o.w = pack_hi16(ubyte_f32<2>(w1), ubyte_f32<3>(w1));
+    return __builtin_bit_cast(mfma_bf16x8, o);
+}
+
+// k-step `ks` (0 .. BLK/32 - 1) of a lane's 16-byte block
+template <int BITS>
+__device__ __forceinline__ mfma_bf16x8 frag_of(const uint4& blk, int ks) {
+    const unsigned w[4] = {blk.x, blk.y, blk.z, blk.w};
+    if constexpr (BITS == 4) return frag_q4(w[ks]);
+    else return frag_q8(w[2 * ks], w[2 * ks + 1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// image builders
+// ------------------------------------------------------------------------------------------------
+size_t quant_q_bytes(int N, int K, int bits) { return (size_t)N * K * bits / 8; }
+size_t quant_sb_bytes(int N, int K, int sb_f32) { return (size_t)N * (K / 64) * 2 * (sb_f32 ? 4 : 2); }
+
+__global__ void quant_pack_q_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int N, int K, int bits) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one destination uint4 per thread
+    const int BLK = bits == 4 ? 128 : 64;
+    const long total = (long)N * K / BLK * 4;                                // (N/16) * (K/BLK) * 64
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), nblk = K / BLK;
+    const long blk = idx >> 6;
+    const int kb = (int)(blk % nblk);
+    const long tile = blk / nblk;
+    const long row = tile * 16 + (lane & 15);
+    const int fc = lane >> 4, wpr = K * bits / 32;
+    uint4 o;
+    unsigned* ow = reinterpret_cast<unsigned*>(&o);
+    if (bits == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ow[i] = src[row * wpr + (kb * 4 + i) * 4 + fc];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ow[2 * i + h] = src[row * wpr + (kb * 2 + i) * 8 + fc * 2 + h];
+    }
+    reinterpret_cast<uint4*>(dst)[idx] = o;
+}
+
+// sb image [tile][which][row 16][g]: element size esz, plain copy with the tile interleave
+__global__ void quant_pack_sb_kernel(const char* __restrict__ scales, const char* __restrict__ biases, char* __restrict__ dst,
+                                     int N, int G, int esz) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one element of scales AND of biases
+    if (idx >= (long)N * G) return;
+    const long row = idx / G, tile = row >> 4;
+    const int g = (int)(idx - row * G), r = (int)(row & 15);
+    const long d0 = ((tile * 2 + 0) * 16 + r) * G + g, d1 = ((tile * 2 + 1) * 16 + r) * G + g;
+    for (int b = 0; b < esz; ++b) { dst[d0 * esz + b] = scales[idx * esz + b]; dst[d1 * esz + b] = biases[idx * esz + b]; }
+}
+
+void quant_pack_launch(const QuantRaw& src, uint32_t* qp, void* sb, hipStream_t s) {
+    if (src.N % 16 != 0 || src.K % 128 != 0 || (src.bits != 4 && src.bits != 8))
+        throw std::invalid_argument("quant pack: N must be a multiple of 16, K of 128, bits 4 or 8");
+    const int BLK = src.bits == 4 ? 128 : 64;
+    const long total = (long)src.N * src.K / BLK * 4;
+    hipLaunchKernelGGL(quant_pack_q_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, src.wq, qp, src.N, src.K, src.bits);
+    const int G = src.K / 64;
+    hipLaunchKernelGGL(quant_pack_sb_kernel, dim3(cdiv((long)src.N * G, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const char*>(src.scales), reinterpret_cast<const char*>(src.biases),
+                       reinterpret_cast<char*>(sb), src.N, G, src.sb_f32 ? 4 : 2);
+}
+
+__global__ void quant_dequant_rows_kernel(QuantRaw q, int r0, bf16_t* __restrict__ out) {
+    const long row = blockIdx.x;
+    uint4* dst = reinterpret_cast<uint4*>(out + row * q.K);
+    for (int c = threadIdx.x; c < q.K / 8; c += blockDim.x) dst[c] = quant_dequant_chunk(q, r0 + row, c);
+}
+
+void quant_dequant_rows_launch(const QuantRaw& src, int r0, int nrows, bf16_t* out, hipStream_t s) {
+    if (nrows <= 0) return;
+    if (src.K % 64 != 0) throw std::invalid_argument("quantised matrix: K must be a multiple of the group size 64");
+    hipLaunchKernelGGL(quant_dequant_rows_kernel, dim3(nrows), dim3(128), 0, s, src, r0, out);
+}
+
+__global__ void embed_splice_q_kernel(const int* __restrict__ ids, const int* __restrict__ audio_src, QuantRaw q,
+                                      const bf16_t* __restrict__ audio, bf16_t* __restrict__ x, int H) {
+    const int p = blockIdx.x, a = audio_src ? audio_src[p] : -1;
+    uint4* dst = reinterpret_cast<uint4*>(x + (long)p * H);
+    if (a >= 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(audio + (long)a * H);
+        for (int i = threadIdx.x; i < H / 8; i += blockDim.x) dst[i] = src[i];
+    } else {
+        const long row = ids[p];
+        for (int i = threadIdx.x; i < H / 8; i += blockDim.x) dst[i] = quant_dequant_chunk(q, row, i);
+    }
+}
+
+void embed_splice_q_launch(const int* ids, const int* audio_src, const QuantRaw& embed, const bf16_t* audio, bf16_t* x,
+                           int n_pos, int H, hipStream_t s) {
+    if (n_pos <= 0) return;
+    hipLaunchKernelGGL(embed_splice_q_kernel, dim3(n_pos), dim3(128), 0, s, ids, audio_src, embed, audio, x, H);
+}
+
+void gather_rows_q_launch(const QuantRaw& embed, const int* row_idx, bf16_t* dst, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(embed_splice_q_kernel, dim3(n), dim3(128), 0, s, row_idx, (const int*)nullptr, embed, (const bf16_t*)nullptr,
+                       dst, embed.K);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tuned decode-step kernel.  Same skeleton as decode_gemv2_kernel (dec_kernels.hip): a workgroup = one 16-row weight tile
+// group (NT tiles) x 16 batch rows; activation loads first, then ALL packed weights of the wave (a whole matrix is
+// 1 - 4 MB at 4 bit: in flight at once), activations staged through LDS with the RMSNorm applied on the way, k-blocks
+// interleaved over the waves, fixed-order cross-wave reduction.  Differences:
+//   * MFMA operands are swapped (A = activations, B = weights) so a lane owns ONE weight row (n = lane & 15) and four
+//     batch rows: one scale / bias per group per lane instead of four;
+//   * per 64-column group: acc = sum q x (two 16x16x32 MFMAs from a zero accumulator), then
+//     tot += scale * acc + bias * xsum[batch row], xsum = f32 sum of the staged (bf16) activations of that group, built
+//     by the staging threads with three shuffles per chunk.
+// ------------------------------------------------------------------------------------------------
+enum { QPRO_COPY = 0, QPRO_RMSNORM = 1 };
+
+struct DecGemvQArgs {
+    DecGemvArgs g;
+    const uint32_t* qp;
+    const void* sb;
+    const bf16_t* norm_w;
+    float eps;
+};
+
+template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a2) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    constexpr int BLK = BITS == 4 ? 128 : 64, GPB = BLK / 64;
+    constexpr int K = KBW * WAVES * BLK, G = K / 64, KCH = K / 8, XSTRIDE = 2 * K + 16;
+    constexpr int TPR = WAVES * 64 / 16, XI = KCH / TPR;
+    static_assert(TPR % 8 == 0 && TPR <= 64 && KCH % TPR == 0, "row staging geometry");
+    DecGemvArgs a = a2.g;
+    {
+        const int r0 = blockIdx.y * 16;
+        a.X += (long)r0 * K;
+        a.out += (long)r0 * (EPI == DEC_EPI_SWIGLU ? a.N / 2 : a.N);
+        a.B = a.B - r0 < 16 ? a.B - r0 : 16;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    const int n0 = blockIdx.x * 16 * NT;
+    char* s_x = dsm;                                                          // [16][XSTRIDE] bf16
+    float* s_xs = reinterpret_cast<float*>(dsm + 16 * XSTRIDE);               // [G][16] group sums
+    float* s_red = s_xs + G * 16;                                             // [WAVES][NT][16 batch][16 n]
+    const int srow = tid / TPR, scol = tid % TPR;
+    // ---- 1. activation loads (clamped row, zeroed by a select) --------------------------------------------
+    uint4 xr[XI];
+    {
+        const bf16_t* xp = a.X + (long)(srow < a.B ? srow : 0) * K + scol * 8;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+        if (srow >= a.B) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xr[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // ---- 2. every packed weight block of this wave + the scales / biases of its groups --------------------
+    uint4 wq[NT][KBW];
+    float sc[NT][KBW][GPB], bi[NT][KBW][GPB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long tile = n0 / 16 + t;
+        const uint32_t* qp = a2.qp + (tile * (K / BLK) * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) wq[t][i] = *reinterpret_cast<const uint4*>(qp + (long)(wave + WAVES * i) * 256);
+#pragma unroll
+        for (int i = 0; i < KBW; ++i)
+#pragma unroll
+            for (int h = 0; h < GPB; ++h) {
+                const int g = (wave + WAVES * i) * GPB + h;
+                sc[t][i][h] = sb_at<SBF32>(a2.sb, ((tile * 2 + 0) * 16 + fr) * G + g);
+                bi[t][i][h] = sb_at<SBF32>(a2.sb, ((tile * 2 + 1) * 16 + fr) * G + g);
+            }
+    }
+    // epilogue lane map: batch row = lane >> 2, four consecutive n at (lane & 3) * 4
+    const int erow = lane >> 2, eq = lane & 3;
+    uint2 rsd[NT][1];
+    if constexpr (EPI == DEC_EPI_RESID) {
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                rsd[t][0] = *reinterpret_cast<const uint2*>(a.out + (long)(erow < a.B ? erow : 0) * a.N + n0 + t * 16 + eq * 4);
+        }
+    }
+    // ---- 3. activation rows -> LDS (+ RMSNorm), group sums of the staged values -----------------------------
+    {
+        char* xrow = s_x + (size_t)srow * XSTRIDE + scol * 16;
+        float inv = 0.0f;
+        if constexpr (PRO == QPRO_RMSNORM) {
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
+            }
+#pragma unroll
+            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            inv = rsqrtf(ss / (float)K + a2.eps);
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            uint4 o = xr[i];
+            if constexpr (PRO == QPRO_RMSNORM) {
+                const uint4 nw = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+                const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
+                bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) oe[j] = f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv));
+            }
+            *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
+            const bf16_t* oe = reinterpret_cast<const bf16_t*>(&o);
+            float p = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p += bf16_to_f32(oe[j]);
+            // chunk c = scol + TPR * i belongs to group c / 8: the 8 chunks of a group sit on 8 adjacent lanes
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 4, 64);
+            if ((scol & 7) == 0) s_xs[((scol + TPR * i) >> 3) * 16 + srow] = p;
+        }
+    }
+    __syncthreads();
+    // ---- 4. per group: two MFMAs from zero, then scale / bias on the vector unit ----------------------------
+    f32x4 tot[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KBW; ++i) {
+        const int blk = wave + WAVES * i;
+#pragma unroll
+        for (int h = 0; h < GPB; ++h) {
+            const int g = blk * GPB + h;
+            const f32x4 xs = *reinterpret_cast<const f32x4*>(s_xs + g * 16 + fc * 4);
+            const uint4 x0 = *reinterpret_cast<const uint4*>(s_x + (size_t)fr * XSTRIDE + ((g * 2 + 0) * 32 + fc * 8) * 2);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(s_x + (size_t)fr * XSTRIDE + ((g * 2 + 1) * 32 + fc * 8) * 2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x0), frag_of<BITS>(wq[t][i], 2 * h + 0), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x1), frag_of<BITS>(wq[t][i], 2 * h + 1), acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tot[t][j] += sc[t][i][h] * acc[j] + bi[t][i][h] * xs[j];
+            }
+        }
+    }
+    // ---- 5. cross-wave reduction in fixed order through a [batch][n] image, epilogue on wave 0 ---------------
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_red[((size_t)(wave * NT + t) * 16 + fc * 4 + j) * 16 + fr] = tot[t][j];
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 acc[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv)
+            acc[t][0] += *reinterpret_cast<const f32x4*>(s_red + ((size_t)(wv * NT + t) * 16 + erow) * 16 + eq * 4);
+    }
+    if constexpr (EPI == DEC_EPI_RESID) dec_epilogue<NT, 1, EPI>(a, acc, n0, erow, eq, rsd);
+    else dec_epilogue<NT, 1, EPI>(a, acc, n0, erow, eq);
+}
+
+template <int BITS, int WAVES, int KBW, int NT>
+constexpr size_t gemvq_lds() {
+    constexpr int K = KBW * WAVES * (BITS == 4 ? 128 : 64);
+    return (size_t)16 * (2 * K + 16) + (size_t)(K / 64) * 16 * 4 + (size_t)WAVES * NT * 1024;
+}
+
+template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI>
+static bool gemvq_go(const DecGemvQArgs& a2, hipStream_t s) {
+    constexpr size_t lds = gemvq_lds<BITS, WAVES, KBW, NT>();
+    static_assert(lds <= 156 * 1024, "LDS image too large");
+    auto kern = decode_gemvq_kernel<BITS, SBF32, NT, WAVES, KBW, PRO, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), (a2.g.B + 15) / 16), dim3(WAVES * 64), lds, s, a2);
+    return true;
+}
+
+// (K, bits) -> k-blocks per wave at 8 waves; false: no tuned instantiation
+template <int BITS, bool SBF32, int NT, int PRO, int EPI>
+static bool gemvq_k(const DecGemvQArgs& a2, hipStream_t s) {
+    constexpr int M = BITS == 4 ? 1 : 2;           // 8 bit: half the columns per 16-byte block
+    switch (a2.g.K) {
+        case 1024: return gemvq_go<BITS, SBF32, NT, 8, 1 * M, PRO, EPI>(a2, s);
+        case 2048: return gemvq_go<BITS, SBF32, NT, 8, 2 * M, PRO, EPI>(a2, s);
+        case 3072:
+            if constexpr (PRO == QPRO_COPY) return gemvq_go<BITS, SBF32, NT, 8, 3 * M, PRO, EPI>(a2, s);
+            else return false;
+        default: return false;
+    }
+}
+
+template <int BITS, bool SBF32>
+static bool gemvq_epi(DecEpi epi, bool norm, const DecGemvQArgs& a2, hipStream_t s) {
+    if (norm && epi == DEC_EPI_BF16) return gemvq_k<BITS, SBF32, 1, QPRO_RMSNORM, DEC_EPI_BF16>(a2, s);
+    if (norm && epi == DEC_EPI_SWIGLU) return gemvq_k<BITS, SBF32, 2, QPRO_RMSNORM, DEC_EPI_SWIGLU>(a2, s);
+    if (!norm && epi == DEC_EPI_RESID) return gemvq_k<BITS, SBF32, 1, QPRO_COPY, DEC_EPI_RESID>(a2, s);
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic kernel for shapes without a tuned instantiation (test geometries, K = 6144): one workgroup per output column,
+// thread b = batch row, the factored sum on the vector unit straight from the row-major triplet.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float qdot_row(const QuantRaw& q, long row, const bf16_t* __restrict__ x) {
+    const int G = q.K / 64;
+    float tot = 0.0f;
+    for (int g = 0; g < G; ++g) {
+        float acc = 0.0f, xs = 0.0f;
+        for (int c = 0; c < 8; ++c) {
+            const int ch = g * 8 + c;
+            unsigned e[8];
+            if (q.bits == 4) {
+                const uint32_t w = q.wq[row * (q.K / 8) + ch];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = (w >> (4 * j)) & 0xFu;
+            } else {
+                const uint32_t w0 = q.wq[row * (q.K / 4) + 2 * ch], w1 = q.wq[row * (q.K / 4) + 2 * ch + 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { e[j] = (w0 >> (8 * j)) & 0xFFu; e[4 + j] = (w1 >> (8 * j)) & 0xFFu; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = bf16_to_f32(x[ch * 8 + j]);
+                acc = fmaf((float)e[j], xv, acc);
+                xs += xv;
+            }
+        }
+        const float s = q.sb_f32 ? reinterpret_cast<const float*>(q.scales)[row * G + g] : bf16_to_f32(reinterpret_cast<const bf16_t*>(q.scales)[row * G + g]);
+        const float b = q.sb_f32 ? reinterpret_cast<const float*>(q.biases)[row * G + g] : bf16_to_f32(reinterpret_cast<const bf16_t*>(q.biases)[row * G + g]);
+        tot += s * acc + b * xs;
+    }
+    return tot;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(64) void gemvq_generic_kernel(DecGemvArgs a, QuantRaw q) {
+    const int col = blockIdx.x, b = threadIdx.x;
+    if (b >= a.B) return;
+    const bf16_t* x = a.X + (long)b * a.K;
+    if constexpr (EPI == DEC_EPI_SWIGLU) {
+        // rows in blocks of 32: 16 gate rows then the 16 matching up rows (engine layout of the fused gate|up matrix)
+        const long rg = (long)(col >> 4) * 32 + (col & 15);
+        a.out[(long)b * (a.N / 2) + col] = f32_to_bf16(swiglu_bf16(qdot_row(q, rg, x), qdot_row(q, rg + 16, x)));
+    } else {
+        const float v = qdot_row(q, col, x);
+        bf16_t* p = a.out + (long)b * a.N + col;
+        if constexpr (EPI == DEC_EPI_RESID) *p = f32_to_bf16(bf16_to_f32(*p) + bf16_round(v));
+        else if constexpr (EPI == DEC_EPI_LOGITS) a.logits[(long)b * a.N + col] = bf16_round(v);
+        else *p = f32_to_bf16(v);
+    }
+}
+
+static void gemvq_generic(DecEpi epi, const DecGemvArgs& a, const QuantRaw& q, hipStream_t s) {
+    if (a.B > 64) throw std::length_error("decode batch > 64 rows");
+    if (q.K % 64 != 0 || q.K != a.K || q.N != a.N) throw std::invalid_argument("quantised gemv: shape mismatch");
+    switch (epi) {
+        case DEC_EPI_BF16: hipLaunchKernelGGL(gemvq_generic_kernel<DEC_EPI_BF16>, dim3(a.N), dim3(64), 0, s, a, q); break;
+        case DEC_EPI_RESID: hipLaunchKernelGGL(gemvq_generic_kernel<DEC_EPI_RESID>, dim3(a.N), dim3(64), 0, s, a, q); break;
+        case DEC_EPI_SWIGLU: hipLaunchKernelGGL(gemvq_generic_kernel<DEC_EPI_SWIGLU>, dim3(a.N / 2), dim3(64), 0, s, a, q); break;
+        case DEC_EPI_LOGITS: hipLaunchKernelGGL(gemvq_generic_kernel<DEC_EPI_LOGITS>, dim3(a.N), dim3(64), 0, s, a, q); break;
+    }
+}
+
+void decode_gemv_q_launch(DecEpi epi, const DecGemvArgs& a, const QuantImg& w, const bf16_t* norm_w, float eps,
+                          bf16_t* norm_scratch, hipStream_t s) {
+    if (a.B <= 0) return;
+    const int nt = epi == DEC_EPI_SWIGLU ? 2 : 1;
+    bool ok = false;
+    if (w.qp && a.B <= 64 && a.N % (16 * nt) == 0 && epi != DEC_EPI_LOGITS) {
+        DecGemvQArgs a2{a, w.qp, w.sb, norm_w, eps};
+        if (w.bits == 4) ok = w.sb_f32 ? gemvq_epi<4, true>(epi, norm_w != nullptr, a2, s) : gemvq_epi<4, false>(epi, norm_w != nullptr, a2, s);
+        else if (w.bits == 8) ok = w.sb_f32 ? gemvq_epi<8, true>(epi, norm_w != nullptr, a2, s) : gemvq_epi<8, false>(epi, norm_w != nullptr, a2, s);
+    }
+    if (ok) return;
+    DecGemvArgs g = a;
+    if (norm_w) {
+        rmsnorm_rows_launch(a.X, norm_w, norm_scratch, a.B, a.K, eps, s);
+        g.X = norm_scratch;
+    }
+    gemvq_generic(epi, g, w.raw, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LM head on the quantised tied embedding, persistent form (cf. lm_head_kernel): batch rows normalised and staged once
+// per workgroup together with their group sums; every wave walks its own 16-row tiles over the full K with a two-deep
+// register pipeline (q blocks + the tile's scales / biases), no cross-wave reduction.  A lane owns weight row
+// n = tile * 16 + (lane & 15) and batch rows 4 (lane >> 4) .. + 3 of each batch tile; running argmax per batch row over
+// bf16-rounded logits, lowest index on ties.
+// ------------------------------------------------------------------------------------------------
+constexpr int LMQ_WAVES = 8;
+
+struct LmHeadQArgs {
+    const uint32_t* qp;
+    const void* sb;
+    const bf16_t* X;
+    const bf16_t* norm_w;
+    float eps;
+    int B, N;
+    float* logits;
+    float* part_val;
+    int* part_idx;
+};
+
+template <int BITS, bool SBF32, int K, int NB>
+__global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    constexpr int BLK = BITS == 4 ? 128 : 64, GPB = BLK / 64, NBLK = K / BLK, G = K / 64;
+    constexpr int KCH = K / 8, XSTRIDE = 2 * K + 16, TPR = 32, XI = KCH / TPR;
+    constexpr int SBV = G * (SBF32 ? 4 : 2) / 16;                 // 16-byte loads per lane for the scales (and for the biases)
+    static_assert(G * (SBF32 ? 4 : 2) % 16 == 0, "scale row must be a whole number of 16-byte loads");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    char* s_x = dsm;                                                            // [NB*16][XSTRIDE]
+    float* s_xs = reinterpret_cast<float*>(dsm + (size_t)NB * 16 * XSTRIDE);     // [G][NB*16]
+    const int total_waves = gridDim.x * LMQ_WAVES, gw = blockIdx.x * LMQ_WAVES + wave;
+    const int ntiles = a.N / 16;
+    const int my_tiles = gw < ntiles ? (ntiles - gw + total_waves - 1) / total_waves : 0;
+    uint4 qa[NBLK], qb[NBLK], sa[2 * SBV], sbb[2 * SBV];
+    auto issue = [&](uint4 (&q)[NBLK], uint4 (&sv)[2 * SBV], int item) {
+        const long tile = gw + (long)item * total_waves;
+        const uint32_t* qp = a.qp + (tile * NBLK * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) q[i] = *reinterpret_cast<const uint4*>(qp + (long)i * 256);
+        const char* sp = reinterpret_cast<const char*>(a.sb) + ((tile * 2 * 16 + fr) * G) * (SBF32 ? 4 : 2);
+#pragma unroll
+        for (int i = 0; i < SBV; ++i) {
+            sv[i] = *reinterpret_cast<const uint4*>(sp + i * 16);
+            sv[SBV + i] = *reinterpret_cast<const uint4*>(sp + (size_t)16 * G * (SBF32 ? 4 : 2) + i * 16);
+        }
+    };
+    if (my_tiles > 0) issue(qa, sa, 0);
+    // ---- stage + RMSNorm the batch rows, 16 rows per pass; group sums of the staged values ------------------
+    {
+        const int srow = tid / TPR, scol = tid % TPR;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int r = nb * 16 + srow;
+            const bool live = r < a.B;
+            const bf16_t* xp = a.X + (long)(live ? r : 0) * K + scol * 8;
+            uint4 xr[XI];
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
+            }
+#pragma unroll
+            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            const float inv = rsqrtf(ss / (float)K + a.eps);
+            char* xrow = s_x + (size_t)r * XSTRIDE + scol * 16;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const uint4 nw = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
+                const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
+                uint4 o;
+                bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+                float p = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    oe[j] = live ? f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv)) : (bf16_t)0;
+                    p += bf16_to_f32(oe[j]);
+                }
+                *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
+                p += __shfl_xor(p, 1, 64);
+                p += __shfl_xor(p, 2, 64);
+                p += __shfl_xor(p, 4, 64);
+                if ((scol & 7) == 0) s_xs[((scol + TPR * i) >> 3) * (NB * 16) + r] = p;
+            }
+        }
+    }
+    __syncthreads();
+    float best[NB][4];
+    int bidx[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { best[b][j] = -INFINITY; bidx[b][j] = 0x7fffffff; }
+    auto consume = [&](const uint4 (&q)[NBLK], const uint4 (&sv)[2 * SBV], int item) {
+        const int tile = gw + item * total_waves, n = tile * 16 + fr;
+        f32x4 tot[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tot[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+            for (int h = 0; h < GPB; ++h) {
+                const int g = i * GPB + h;
+                float s, bv;
+                if constexpr (SBF32) {
+                    s = reinterpret_cast<const float*>(&sv[0])[g];
+                    bv = reinterpret_cast<const float*>(&sv[SBV])[g];
+                } else {
+                    s = bf16_to_f32(reinterpret_cast<const bf16_t*>(&sv[0])[g]);
+                    bv = bf16_to_f32(reinterpret_cast<const bf16_t*>(&sv[SBV])[g]);
+                }
+                const mfma_bf16x8 w0 = frag_of<BITS>(q[i], 2 * h + 0), w1 = frag_of<BITS>(q[i], 2 * h + 1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const char* xb = s_x + (size_t)(b * 16 + fr) * XSTRIDE + fc * 16;
+                    const uint4 x0 = *reinterpret_cast<const uint4*>(xb + (g * 2 + 0) * 64);
+                    const uint4 x1 = *reinterpret_cast<const uint4*>(xb + (g * 2 + 1) * 64);
+                    const f32x4 xs = *reinterpret_cast<const f32x4*>(s_xs + g * (NB * 16) + b * 16 + fc * 4);
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x0), w0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x1), w1, acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tot[b][j] += s * acc[j] + bv * xs[j];
+                }
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = b * 16 + fc * 4 + j;
+                const float v = bf16_round(tot[b][j]);
+                if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
+                if (v > best[b][j] || (v == best[b][j] && n < bidx[b][j])) { best[b][j] = v; bidx[b][j] = n; }
+            }
+    };
+    for (int item = 0; item < my_tiles; item += 2) {
+        if (item + 1 < my_tiles) issue(qb, sbb, item + 1);
+        consume(qa, sa, item);
+        if (item + 1 < my_tiles) {
+            if (item + 2 < my_tiles) issue(qa, sa, item + 2);
+            consume(qb, sbb, item + 1);
+        }
+    }
+    // ---- argmax partial of the workgroup: over the 16 weight rows of a lane group, then over the waves ----------
+    float* s_v = reinterpret_cast<float*>(dsm);                                   // the activation image is dead now
+    int* s_i = reinterpret_cast<int*>(dsm + LMQ_WAVES * NB * 16 * sizeof(float));
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int ofs = 1; ofs < 16; ofs <<= 1) {
+                const float ov = __shfl_xor(best[b][j], ofs, 64);
+                const int oi = __shfl_xor(bidx[b][j], ofs, 64);
+                if (ov > best[b][j] || (ov == best[b][j] && oi < bidx[b][j])) { best[b][j] = ov; bidx[b][j] = oi; }
+            }
+            if (fr == 0) {
+                s_v[(wave * NB + b) * 16 + fc * 4 + j] = best[b][j];
+                s_i[(wave * NB + b) * 16 + fc * 4 + j] = bidx[b][j];
+            }
+        }
+    __syncthreads();
+    if (tid < NB * 16 && tid < a.B) {
+        const int b = tid >> 4, r = tid & 15;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < LMQ_WAVES; ++w) {
+            const float ov = s_v[(w * NB + b) * 16 + r];
+            const int oi = s_i[(w * NB + b) * 16 + r];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        a.part_val[(long)tid * gridDim.x + blockIdx.x] = bv;
+        a.part_idx[(long)tid * gridDim.x + blockIdx.x] = bi;
+    }
+}
+
+constexpr int LMQ_GRID = 256;
+
+static bool lm_head_q_supported(int N, int K, int bits) {
+    return (K == 1024 || K == 2048) && (bits == 4 || bits == 8) && N % 16 == 0 && N / 16 >= LMQ_GRID * LMQ_WAVES;
+}
+int lm_head_q_parts(int N, int K, int bits) { return lm_head_q_supported(N, K, bits) ? LMQ_GRID : 1; }
+
+template <int BITS, bool SBF32, int K, int NB>
+static void lm_head_q_go(const LmHeadQArgs& a, hipStream_t s) {
+    constexpr size_t lds = (size_t)NB * 16 * (2 * K + 16) + (size_t)(K / 64) * NB * 16 * 4;
+    auto kern = lm_head_q_kernel<BITS, SBF32, K, NB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(LMQ_GRID), dim3(LMQ_WAVES * 64), lds, s, a);
+}
+
+template <int BITS, bool SBF32, int K>
+static void lm_head_q_nb(const LmHeadQArgs& a, hipStream_t s) {
+    switch ((a.B + 15) / 16) {
+        case 1: lm_head_q_go<BITS, SBF32, K, 1>(a, s); break;
+        case 2: lm_head_q_go<BITS, SBF32, K, 2>(a, s); break;
+        case 3: if constexpr (K == 1024) { lm_head_q_go<BITS, SBF32, K, 3>(a, s); break; }
+        case 4: if constexpr (K == 1024) { lm_head_q_go<BITS, SBF32, K, 4>(a, s); break; }
+        default: throw std::length_error("LM head: batch rows exceed the LDS image at this hidden size");
+    }
+}
+
+// generic path: logits of every row to `logits_scratch`, then one argmax partial per row
+__global__ __launch_bounds__(256) void argmax_f32_rows_kernel(const float* __restrict__ x, int n, float* __restrict__ part_val,
+                                                              int* __restrict__ part_idx) {
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    const float* row = x + (long)blockIdx.x * n;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = row[i];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    s_v[threadIdx.x] = bv;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int ofs = 128; ofs > 0; ofs >>= 1) {
+        if ((int)threadIdx.x < ofs) {
+            const float ov = s_v[threadIdx.x + ofs];
+            const int oi = s_i[threadIdx.x + ofs];
+            if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) { s_v[threadIdx.x] = ov; s_i[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part_val[blockIdx.x] = s_v[0]; part_idx[blockIdx.x] = s_i[0]; }
+}
+
+int lm_head_q_launch(const QuantImg& w, const bf16_t* X, const bf16_t* norm_w, float eps, int B, int N, int K, float* logits,
+                     float* part_val, int* part_idx, bf16_t* norm_scratch, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (w.qp && lm_head_q_supported(N, K, w.bits)) {
+        LmHeadQArgs a{w.qp, w.sb, X, norm_w, eps, B, N, logits, part_val, part_idx};
+#define QASR_LMQ(BITS_, F32_)                                                              \
+        do { if (K == 1024) lm_head_q_nb<BITS_, F32_, 1024>(a, s); else lm_head_q_nb<BITS_, F32_, 2048>(a, s); } while (0)
+        if (w.bits == 4) { if (w.sb_f32) QASR_LMQ(4, true); else QASR_LMQ(4, false); }
+        else { if (w.sb_f32) QASR_LMQ(8, true); else QASR_LMQ(8, false); }
+#undef QASR_LMQ
+        return LMQ_GRID;
+    }
+    // generic: needs a logits buffer (the engine always passes one on this path)
+    if (!logits) throw std::invalid_argument("quantised LM head (generic path) needs the logits buffer");
+    DecGemvArgs g{};
+    g.X = X; g.B = B; g.N = N; g.K = K; g.logits = logits;
+    rmsnorm_rows_launch(X, norm_w, norm_scratch, B, K, eps, s);
+    g.X = norm_scratch;
+    gemvq_generic(DEC_EPI_LOGITS, g, w.raw, s);
+    hipLaunchKernelGGL(argmax_f32_rows_kernel, dim3(B), dim3(256), 0, s, logits, N, part_val, part_idx);
+    return 1;
+}
+
+}  // namespace qasr

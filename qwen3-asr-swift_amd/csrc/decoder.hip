@@ -31,6 +31,15 @@ __global__ void interleave_gate_up_kernel(const bf16_t* __restrict__ gate, const
     for (int i = threadIdx.x; i < H / 8; i += blockDim.x) d4[i] = s4[i];
 }
 
+// dst rows in blocks of 32: 16 rows of `a` then the 16 matching rows of `b` (byte rows: packed q, scales, biases)
+__global__ void interleave_rows_bytes_kernel(const char* __restrict__ a, const char* __restrict__ b, char* __restrict__ dst,
+                                             int row_bytes) {
+    const int r = blockIdx.x, blk = r >> 5, w = r & 31;
+    const char* src = (w < 16 ? a : b) + (long)(blk * 16 + (w & 15)) * row_bytes;
+    char* d = dst + (long)r * row_bytes;
+    for (int i = threadIdx.x; i < row_bytes; i += blockDim.x) d[i] = src[i];
+}
+
 __global__ void narrow_f32_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = f32_to_bf16(src[i]);
@@ -62,14 +71,69 @@ const bf16_t* Engine::packed_copy(const bf16_t* w, int N, int K) {
     return p;
 }
 
+// A quantised Linear / embedding of the checkpoint: `stem.weight` uint32 [N][K * bits / 32], `stem.scales`, `stem.biases`
+// [N][K / 64] in bf16 or f32 (Sources/MLXCommon/WeightLoading.swift:48-96; bits from the preset, Qwen3ASR.swift:581-601)
+QuantRaw Engine::quant_raw(const std::string& stem, int N, int K) const {
+    const int bits = cfg_.bits;
+    if (bits != 4 && bits != 8) throw std::runtime_error("quantised tensors need qasr_config.bits = 4 or 8 (got " + std::to_string(bits) + ")");
+    if (cfg_.group_size != 64 || K % 64 != 0) throw std::runtime_error(stem + ": only group size 64 is supported");
+    const Tensor &w = tensor(stem + ".weight"), &sc = tensor(stem + ".scales"), &bi = tensor(stem + ".biases");
+    if (w.dtype != QASR_DTYPE_U32 || w.shape != std::vector<int64_t>{N, (int64_t)K * bits / 32})
+        throw std::runtime_error(stem + ".weight: expected uint32 [" + std::to_string(N) + ", " + std::to_string(K * bits / 32) + "] (bits / shape mismatch)");
+    for (const Tensor* t : {&sc, &bi}) {
+        if (t->shape != std::vector<int64_t>{N, (int64_t)K / 64}) throw std::runtime_error(stem + ": scales / biases must be [out, in / 64]");
+        if (t->dtype != QASR_DTYPE_BF16 && t->dtype != QASR_DTYPE_F32) throw std::runtime_error(stem + ": scales / biases must be bf16 or f32");
+    }
+    if (sc.dtype != bi.dtype) throw std::runtime_error(stem + ": scales and biases differ in dtype");
+    QuantRaw q;
+    q.wq = w.buf.as<uint32_t>(); q.scales = sc.buf.p; q.biases = bi.buf.p;
+    q.sb_f32 = sc.dtype == QASR_DTYPE_F32; q.N = N; q.K = K; q.bits = bits;
+    return q;
+}
+
+// decode-step images of a quantised matrix (dec_quant.h); shapes the tuned kernels cannot take keep only the triplet
+QuantImg Engine::quant_image(const QuantRaw& raw) {
+    QuantImg img;
+    img.raw = raw; img.bits = raw.bits; img.sb_f32 = raw.sb_f32;
+    if (raw.N % 16 != 0 || raw.K % 128 != 0) return img;
+    auto qp = std::make_unique<DevBuf>(), sb = std::make_unique<DevBuf>();
+    qp->alloc(quant_q_bytes(raw.N, raw.K, raw.bits));
+    sb->alloc(quant_sb_bytes(raw.N, raw.K, raw.sb_f32));
+    quant_pack_launch(raw, qp->as<uint32_t>(), sb->p, stream_);
+    img.qp = qp->as<uint32_t>(); img.sb = sb->p;
+    fused_.push_back(std::move(qp));
+    fused_.push_back(std::move(sb));
+    return img;
+}
+
+void Engine::embed_rows(const int* d_ids, bf16_t* dst, int n, hipStream_t s) {
+    if (decw_.quant) gather_rows_q_launch(decw_.embed_raw, d_ids, dst, n, s);
+    else gather_rows_launch(decw_.embed, d_ids, dst, n, cfg_.hidden, s);
+}
+
 void Engine::finalize_decoder() {
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nkv = cfg_.kv_heads * hd, I = cfg_.inter;
     if (cfg_.inter % 16 != 0 || H % 32 != 0) throw std::invalid_argument("decoder widths must be multiples of 16/32");
-    decw_.embed = wptr("model.embed_tokens.weight", {cfg_.vocab, H});
-    decw_.norm = wptr("model.norm.weight", {H});
     // an aligner engine runs the prompt pass only: no decode-step weight images, one K cache shared by all layers
     const bool aligner = cfg_.classify_num > 0;
-    decw_.embed_p = aligner ? nullptr : packed_copy(decw_.embed, cfg_.vocab, H);
+    // MLX-quantised checkpoint (QuantizedTextModel: every decoder Linear + the tied embedding are triplets) or float
+    decw_ = DecW{};
+    decw_.quant = tensors_.count("model.embed_tokens.scales") > 0;
+    decw_.norm = wptr("model.norm.weight", {H});
+    auto new_buf = [&](size_t bytes) {
+        auto b = std::make_unique<DevBuf>();
+        b->alloc(bytes);
+        void* p = b->p;
+        fused_.push_back(std::move(b));
+        return p;
+    };
+    if (decw_.quant) {
+        decw_.embed_raw = quant_raw("model.embed_tokens", cfg_.vocab, H);
+        if (!aligner) decw_.embed_q = quant_image(decw_.embed_raw);
+    } else {
+        decw_.embed = wptr("model.embed_tokens.weight", {cfg_.vocab, H});
+        decw_.embed_p = aligner ? nullptr : packed_copy(decw_.embed, cfg_.vocab, H);
+    }
     if (aligner) {
         if (cfg_.classify_num % 4 != 0) throw std::invalid_argument("classify_num must be a multiple of 4");
         decw_.cls_w = wptr("lm_head.weight", {cfg_.classify_num, H});
@@ -78,11 +142,54 @@ void Engine::finalize_decoder() {
     decw_.layers.clear();
     for (int i = 0; i < cfg_.dec_layers; ++i) {
         const std::string p = "model.layers." + std::to_string(i) + ".";
-        DecLayerW L;
+        DecLayerW L{};
         L.ln1 = wptr(p + "input_layernorm.weight", {H});
         L.ln2 = wptr(p + "post_attention_layernorm.weight", {H});
         L.qn = wptr(p + "self_attn.q_norm.weight", {hd});
         L.kn = wptr(p + "self_attn.k_norm.weight", {hd});
+        if (decw_.quant) {
+            // The prompt pass multiplies by bf16(scale * q + bias) like the reference's many-row kernel (dec_quant.h), so
+            // it keeps its bf16 GEMMs on dequantised copies; the decode step reads the packed images.  q|k|v and gate|up
+            // are fused exactly like the float path: rows concatenated / interleaved in blocks of 16, triplet by triplet.
+            const int bits = cfg_.bits;
+            const QuantRaw rq = quant_raw(p + "self_attn.q_proj", nq, H), rk = quant_raw(p + "self_attn.k_proj", nkv, H),
+                           rv = quant_raw(p + "self_attn.v_proj", nkv, H), ro = quant_raw(p + "self_attn.o_proj", H, nq),
+                           rg = quant_raw(p + "mlp.gate_proj", I, H), ru = quant_raw(p + "mlp.up_proj", I, H),
+                           rd = quant_raw(p + "mlp.down_proj", H, I);
+            const size_t esz = rq.sb_f32 ? 4 : 2;
+            auto cat3 = [&](const void* a, size_t na, const void* b, size_t nb, const void* c, size_t nc) {
+                char* d = (char*)new_buf(na + nb + nc);
+                QASR_HIP(hipMemcpyAsync(d, a, na, hipMemcpyDeviceToDevice, stream_));
+                QASR_HIP(hipMemcpyAsync(d + na, b, nb, hipMemcpyDeviceToDevice, stream_));
+                QASR_HIP(hipMemcpyAsync(d + na + nb, c, nc, hipMemcpyDeviceToDevice, stream_));
+                return (void*)d;
+            };
+            QuantRaw rqkv = rq;
+            rqkv.N = nq + 2 * nkv;
+            const size_t wrow = (size_t)H * bits / 8, srow = (size_t)(H / 64) * esz;
+            rqkv.wq = (const uint32_t*)cat3(rq.wq, nq * wrow, rk.wq, nkv * wrow, rv.wq, nkv * wrow);
+            rqkv.scales = cat3(rq.scales, nq * srow, rk.scales, nkv * srow, rv.scales, nkv * srow);
+            rqkv.biases = cat3(rq.biases, nq * srow, rk.biases, nkv * srow, rv.biases, nkv * srow);
+            QuantRaw rgu = rg;
+            rgu.N = 2 * I;
+            auto inter2 = [&](const void* a, const void* b, size_t row_bytes) {
+                char* d = (char*)new_buf((size_t)2 * I * row_bytes);
+                hipLaunchKernelGGL(interleave_rows_bytes_kernel, dim3(2 * I), dim3(128), 0, stream_, (const char*)a, (const char*)b, d, (int)row_bytes);
+                return (void*)d;
+            };
+            rgu.wq = (const uint32_t*)inter2(rg.wq, ru.wq, wrow);
+            rgu.scales = inter2(rg.scales, ru.scales, srow);
+            rgu.biases = inter2(rg.biases, ru.biases, srow);
+            auto deq = [&](const QuantRaw& r) {
+                bf16_t* d = (bf16_t*)new_buf((size_t)r.N * r.K * sizeof(bf16_t));
+                quant_dequant_rows_launch(r, 0, r.N, d, stream_);
+                return (const bf16_t*)d;
+            };
+            L.wqkv = deq(rqkv); L.wo = deq(ro); L.wgu = deq(rgu); L.wdown = deq(rd);
+            if (!aligner) { L.qkv_q = quant_image(rqkv); L.o_q = quant_image(ro); L.gu_q = quant_image(rgu); L.down_q = quant_image(rd); }
+            decw_.layers.push_back(L);
+            continue;
+        }
         L.wo = wptr(p + "self_attn.o_proj.weight", {H, nq});
         L.wdown = wptr(p + "mlp.down_proj.weight", {H, I});
         const bf16_t* wq = wptr(p + "self_attn.q_proj.weight", {nq, H});
@@ -161,7 +268,7 @@ void Engine::finalize_decoder() {
     d_dattn_.alloc((size_t)B * nq * 2);
     d_dact_.alloc((size_t)B * I * 2);
     d_logits_.alloc((size_t)B * cfg_.vocab * sizeof(float));
-    n_parts_ = lm_head_parts(cfg_.vocab, H);
+    n_parts_ = decw_.quant ? lm_head_q_parts(cfg_.vocab, H, cfg_.bits) : lm_head_parts(cfg_.vocab, H);
     const int parts_cap = std::max(n_parts_, decode_gemv_blocks(DEC_EPI_LOGITS, cfg_.vocab));
     d_part_val_.alloc((size_t)B * parts_cap * sizeof(float));
     d_part_idx_.alloc((size_t)B * parts_cap * sizeof(int));
@@ -291,6 +398,15 @@ void Engine::reset_greedy_state(int max_tokens, bool ignore_eos) {
 
 void Engine::run_lm_head(bool want_logits, int r0, int nr, hipStream_t s) {
     const int H = cfg_.hidden;
+    if (decw_.quant) {
+        // the generic (untuned-shape) quantised head writes every logit and reduces them afterwards: it always needs the buffer
+        const bool need = want_logits || n_parts_ == 1;
+        lm_head_q_launch(decw_.embed_q, d_dx_.as<bf16_t>() + (size_t)r0 * H, decw_.norm, cfg_.rms_eps, nr, cfg_.vocab, H,
+                         need ? d_logits_.as<float>() + (size_t)r0 * cfg_.vocab : nullptr,
+                         d_part_val_.as<float>() + (size_t)r0 * n_parts_, d_part_idx_.as<int>() + (size_t)r0 * n_parts_,
+                         d_dh_.as<bf16_t>() + (size_t)r0 * H, s);
+        return;
+    }
     lm_head_launch(decw_.embed, decw_.embed_p, d_dx_.as<bf16_t>() + (size_t)r0 * H, decw_.norm, cfg_.rms_eps, nr, cfg_.vocab, H,
                    want_logits ? d_logits_.as<float>() + (size_t)r0 * cfg_.vocab : nullptr,
                    d_part_val_.as<float>() + (size_t)r0 * n_parts_, d_part_idx_.as<int>() + (size_t)r0 * n_parts_,
@@ -303,7 +419,8 @@ void Engine::run_prefill(bool want_logits) {
     bf16_t *x = d_px_.as<bf16_t>(), *h = d_ph_.as<bf16_t>(), *qkv = d_pqkv_.as<bf16_t>(), *qr = d_pqr_.as<bf16_t>();
     bf16_t *at = d_pattn_.as<bf16_t>(), *act = d_pact_.as<bf16_t>();
     const int P = n_pos_;
-    embed_splice_launch(d_p_ids_, d_p_audio_src_, decw_.embed, d_audio_.as<bf16_t>(), x, P, H, s);
+    if (decw_.quant) embed_splice_q_launch(d_p_ids_, d_p_audio_src_, decw_.embed_raw, d_audio_.as<bf16_t>(), x, P, H, s);
+    else embed_splice_launch(d_p_ids_, d_p_audio_src_, decw_.embed, d_audio_.as<bf16_t>(), x, P, H, s);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
         const bool aligner = cfg_.classify_num > 0;
@@ -430,28 +547,33 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         unsigned long long* dbg = (stamp_buf_ && l == stamp_layer_) ? stamp_buf_ : nullptr;
         const size_t dbg_stride = (size_t)512 * 16 * 8;
         DecGemvArgs a{};
+        // float checkpoint: fragment-major bf16 images; quantised checkpoint: packed 4 / 8-bit images (dec_quant.h)
+        auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) {
+            if (decw_.quant) decode_gemv_q_launch(epi, a, qi, norm_w, cfg_.rms_eps, h, s);
+            else decode_gemv_fused_launch(epi, a, norm_w, norm_w ? cfg_.rms_eps : 0.f, norm_w ? h : nullptr, s);
+        };
         a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
         decode_gemv_set_debug(dbg);
-        decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, h, s);
+        gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
         const RopeRows rr = rope_rows(r0);
         decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
                                 rr.cos_rows, rr.sin_rows, kv, at, s, dbg ? dbg + 4 * dbg_stride : nullptr);
         a.W = L.wo; a.Wp = L.wo_p; a.X = at; a.N = H; a.K = nq; a.out = x;
         decode_gemv_set_debug(dbg ? dbg + dbg_stride : nullptr);
-        decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
+        gemv(DEC_EPI_RESID, L.o_q, nullptr);
         a.W = L.wgu; a.Wp = L.wgu_p; a.X = x; a.N = 2 * I; a.K = H; a.out = act;
         decode_gemv_set_debug(dbg ? dbg + 2 * dbg_stride : nullptr);
-        decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, h, s);
+        gemv(DEC_EPI_SWIGLU, L.gu_q, L.ln2);
         a.W = L.wdown; a.Wp = L.wdown_p; a.X = act; a.N = H; a.K = I; a.out = x;
         decode_gemv_set_debug(dbg ? dbg + 3 * dbg_stride : nullptr);
-        decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
+        gemv(DEC_EPI_RESID, L.down_q, nullptr);
         decode_gemv_set_debug(nullptr);
     }
     if (!with_head) return;
     run_lm_head(want_logits, r0, nr, s);
     if (greedy)
         greedy_finalize_launch(d_part_val_.as<float>() + (size_t)r0 * n_parts_, d_part_idx_.as<int>() + (size_t)r0 * n_parts_,
-                               n_parts_, gs, nr, 1, decw_.embed, x, H, rope_rows(r0), s);
+                               n_parts_, gs, nr, 1, decw_.embed, x, H, rope_rows(r0), s, decw_.quant ? &decw_.embed_raw : nullptr);
 }
 
 // A whole step = `split` row groups.  The small-batch decode kernels are latency-bound (a 4..12 MB weight
@@ -504,7 +626,7 @@ void Engine::issue_decode_step(int split) {
     // LM head streams 311 MB of tied-embedding weights: once per step for all rows, not once per row group
     run_lm_head(false, 0, B, stream_);
     greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, B, 1, decw_.embed,
-                           d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), stream_);
+                           d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), stream_, decw_.quant ? &decw_.embed_raw : nullptr);
 }
 
 // Greedy loop (Qwen3ASR.swift:344-389): token 0 comes from the prompt pass; every further token costs
@@ -559,7 +681,7 @@ __global__ void set_ints_kernel(int* dst, const int* src, int n) {
 // Slow path (generateSlow, Qwen3ASR.swift:396-433): the logits of every row come back to the host each step and
 // pickNextToken runs on the CPU, exactly like the reference; the step itself is the same HIP decode step.
 void Engine::decode_loop_slow() {
-    const int B = batch_, V = cfg_.vocab, H = cfg_.hidden, stride = cfg_.max_new_tokens + 1;
+    const int B = batch_, V = cfg_.vocab, stride = cfg_.max_new_tokens + 1;
     std::vector<float> logits((size_t)B * V);
     std::vector<std::vector<int32_t>> gen(B);
     std::vector<int> done(B, 0), next(B, 0);
@@ -586,7 +708,7 @@ void Engine::decode_loop_slow() {
         // feed the picked ids: x = embed[token], rope rows for the current positions, one decode step with logits
         std::memcpy(h_tok.p, next.data(), (size_t)B * sizeof(int));
         QASR_HIP(hipMemcpyAsync(d_tok.p, h_tok.p, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream_));
-        gather_rows_launch(decw_.embed, d_tok.as<int>(), d_dx_.as<bf16_t>(), B, H, stream_);
+        embed_rows(d_tok.as<int>(), d_dx_.as<bf16_t>(), B, stream_);
         hipLaunchKernelGGL(refresh_rope_rows_kernel, dim3(B), dim3(64), 0, stream_, gstate_.ctx_len, rope_rows(0));
         run_decode_step(true, false, 0, B, stream_, true);
         hipLaunchKernelGGL(add_scalar_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream_, gstate_.ctx_len, B, 1);
@@ -636,7 +758,7 @@ void Engine::batch_run() {
     run_prefill(slow_path_);
     if (!slow_path_)
         greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, batch_, 0, decw_.embed,
-                               d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), s);
+                               d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), s, decw_.quant ? &decw_.embed_raw : nullptr);
     QASR_HIP(hipEventRecord(ev_[3], s));
     if (slow_path_) decode_loop_slow();
     else decode_loop();
@@ -687,16 +809,20 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     auto body = [&]() {
         DecGemvArgs a{};
         a.B = rows;
+        auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) {
+            if (decw_.quant) decode_gemv_q_launch(epi, a, qi, norm_w, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
+            else decode_gemv_fused_launch(epi, a, norm_w, norm_w ? cfg_.rms_eps : 0.f, norm_w ? d_dh_.as<bf16_t>() : nullptr, s);
+        };
         if (which == 0) {
             // the same four launches as run_decode_step (residual epilogues write a scratch row block)
             a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
-            decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
+            gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
             a.W = L.wo; a.Wp = L.wo_p; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();
-            decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
+            gemv(DEC_EPI_RESID, L.o_q, nullptr);
             a.W = L.wgu; a.Wp = L.wgu_p; a.X = d_dx_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
-            decode_gemv_fused_launch(DEC_EPI_SWIGLU, a, L.ln2, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
+            gemv(DEC_EPI_SWIGLU, L.gu_q, L.ln2);
             a.W = L.wdown; a.Wp = L.wdown_p; a.X = d_dact_.as<bf16_t>(); a.N = H; a.K = I; a.out = d_dh_.as<bf16_t>();
-            decode_gemv_fused_launch(DEC_EPI_RESID, a, nullptr, 0.f, nullptr, s);
+            gemv(DEC_EPI_RESID, L.down_q, nullptr);
         } else if (which == 1) {
             const RopeRows rr = rope_rows(0);
             decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn,
@@ -708,8 +834,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             gemm_nt_swiglu(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, L.wgu, H, n_pos_, 2 * I, H,
                            EpiBiasActBf16<0>{d_pact_.as<bf16_t>(), I, nullptr}, s);
         } else {
-            lm_head_launch(decw_.embed, decw_.embed_p, d_dx_.as<bf16_t>(), decw_.norm, cfg_.rms_eps, batch_, cfg_.vocab, H, nullptr,
-                           d_part_val_.as<float>(), d_part_idx_.as<int>(), d_dh_.as<bf16_t>(), s);
+            run_lm_head(false, 0, batch_, s);
         }
     };
     for (int i = 0; i < 3; ++i) body();
@@ -829,11 +954,13 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         }
     }
     double bytes = 0;
-    if (which == 0) bytes = 2.0 * ((double)nh * hd * H + (double)H * nq + 2.0 * I * H + (double)H * I);
+    // weight bytes per element: 2 (bf16) or bits / 8 + scale and bias per 64 elements
+    const double wbytes = !decw_.quant ? 2.0 : cfg_.bits / 8.0 + 2.0 * (decw_.embed_raw.sb_f32 ? 4.0 : 2.0) / 64.0;
+    if (which == 0) bytes = wbytes * ((double)nh * hd * H + (double)H * nq + 2.0 * I * H + (double)H * I);
     else if (which == 1) { for (int b = 0; b < rows; ++b) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)ctx[b]; }
     else if (which == 3) bytes = 2.0 * (double)n_pos_ * nh * hd * H;          // FLOPs for the GEMM probes
     else if (which == 4) bytes = 2.0 * (double)n_pos_ * 2 * I * H;
-    else bytes = 2.0 * (double)cfg_.vocab * H;
+    else bytes = wbytes * (double)cfg_.vocab * H;
     *bytes_per_launch = bytes;
 }
 
@@ -877,7 +1004,7 @@ void Engine::decode_forced_host(const int32_t* tokens, int n, float* logits) {
         if (tokens[i] < 0 || tokens[i] >= cfg_.vocab) throw std::invalid_argument("token id out of range");
         *idx.as<int>() = tokens[i];
         QASR_HIP(hipMemcpyAsync(didx.p, idx.p, sizeof(int), hipMemcpyHostToDevice, stream_));
-        gather_rows_launch(decw_.embed, didx.as<int>(), d_dx_.as<bf16_t>(), 1, cfg_.hidden, stream_);
+        embed_rows(didx.as<int>(), d_dx_.as<bf16_t>(), 1, stream_);
         hipLaunchKernelGGL(refresh_rope_rows_kernel, dim3(1), dim3(64), 0, stream_, gstate_.ctx_len, rope_rows(0));
         run_decode_step(true, false, 0, 1, stream_, true);
         hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(64), 0, stream_, gstate_.ctx_len, 1, 1);

@@ -4,6 +4,7 @@
 #include "mel.h"
 #include "enc_kernels.h"
 #include "dec_kernels.h"
+#include "dec_quant.h"
 #include "qasr.h"
 #include <map>
 #include <memory>
@@ -144,6 +145,9 @@ private:
     void run_encoder();
     void finalize_decoder();
     const bf16_t* packed_copy(const bf16_t* w, int N, int K);
+    QuantRaw quant_raw(const std::string& stem, int N, int K) const;
+    QuantImg quant_image(const QuantRaw& raw);
+    void embed_rows(const int* d_ids, bf16_t* dst, int n, hipStream_t s);      // dst[i] = embedding row ids[i] (either table)
     void plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio,
                       const std::vector<std::vector<int32_t>>* aligner_tails = nullptr);
     void run_prefill(bool want_logits);
@@ -202,10 +206,14 @@ private:
     struct DecLayerW {
         const bf16_t *ln1, *wqkv, *qn, *kn, *wo, *ln2, *wgu, *wdown;
         const bf16_t *wqkv_p, *wo_p, *wgu_p, *wdown_p;       // fragment-major copies for the decode step
+        QuantImg qkv_q, o_q, gu_q, down_q;                   // quantised checkpoints: packed decode-step images instead
     };
     struct DecW {
         const bf16_t *embed, *norm, *embed_p;
         const bf16_t *cls_w = nullptr, *cls_b = nullptr;       // aligner: Linear(hidden, classify_num) `lm_head.{weight,bias}`
+        bool quant = false;                                    // MLX 4 / 8 bit checkpoint (QuantizedTextModel): packed in HBM
+        QuantRaw embed_raw{};                                  // quantised tied embedding as uploaded (row gather)
+        QuantImg embed_q{};                                    // its LM-head image
         std::vector<DecLayerW> layers;
     } decw_;
     int max_prompt_ = 0, max_ctx_ = 0, max_pos_ = 0, vt_stride_ = 0;

@@ -2,9 +2,9 @@
 // Reference: Sources/Qwen3ASR/WeightLoading.swift:17-126,235-323, Sources/MLXCommon/WeightLoading.swift:48-165.
 //   audio_tower.*  float tensors (f32 / f16 / bf16 on disk)  -> bf16 in HBM
 //   model.*        either float Linear weights (FloatTextDecoder) or MLX affine-quantised triplets
-//                  {weight: uint32 [out, in*bits/32], scales, biases: [out, in/group]} which are
-//                  dequantised here as w = q*scale + bias (f32) and rounded to bf16 -- see DESIGN.md
-//                  (W4/W8 in-kernel dequant is the next scope row N1).
+//                  {weight: uint32 [out, in*bits/32], scales, biases: [out, in/group]}, uploaded AS THEY ARE: the packed
+//                  words stay packed in HBM (csrc/dec_quant.h); scales / biases keep bf16, f16 / f32 ones are widened to
+//                  f32 (exact) so no checkpoint value is rounded.
 #include "engine.h"
 #include "json.h"
 #include <dirent.h>
@@ -100,7 +100,18 @@ void Engine::load_directory(const std::string& dir) {
             if (!dt || !sh || !off || off->arr.size() != 2) throw std::runtime_error("bad tensor entry " + kv.first);
             Entry e;
             e.dtype = dt->str;
-            for (auto& d : sh->arr) e.shape.push_back((int64_t)d.num);
+            for (auto& d : sh->arr) {
+                if (d.type != Json::Num || d.num < 0 || d.num > 9.0e15 || d.num != (double)(int64_t)d.num)
+                    throw std::runtime_error("tensor " + kv.first + ": bad shape entry");
+                e.shape.push_back((int64_t)d.num);
+            }
+            if (e.shape.size() > 8) throw std::runtime_error("tensor " + kv.first + ": too many dimensions");
+            {   // the element count must not overflow: every later size is a product of these
+                unsigned __int128 prod = 1;
+                for (auto d : e.shape) { prod *= (unsigned __int128)d; if (prod > ((unsigned __int128)1 << 48)) throw std::runtime_error("tensor " + kv.first + ": shape too large"); }
+            }
+            if (off->arr[0].type != Json::Num || off->arr[1].type != Json::Num || off->arr[0].num < 0 || off->arr[1].num < 0)
+                throw std::runtime_error("tensor " + kv.first + ": bad data_offsets");
             size_t b = (size_t)off->arr[0].num, en = (size_t)off->arr[1].num;
             if (b > en || en > data_n) throw std::runtime_error("tensor " + kv.first + " out of file bounds");
             e.data = data + b;
@@ -158,22 +169,28 @@ void Engine::load_directory(const std::string& dir) {
             auto si = entries.find(stem + ".scales"), bi = entries.find(stem + ".biases");
             if (si == entries.end() || bi == entries.end()) throw std::runtime_error("quantised " + name + " lacks scales/biases");
             const int bits = cfg_.bits == 8 ? 8 : 4, per = 32 / bits, group = cfg_.group_size;
-            if (e.shape.size() != 2) throw std::runtime_error("quantised " + name + ": expected 2-D");
+            if (group <= 0 || e.shape.size() != 2 || e.shape[0] <= 0 || e.shape[1] <= 0 || e.shape[0] > (1 << 24) || e.shape[1] > (1 << 24))
+                throw std::runtime_error("quantised " + name + ": expected a 2-D uint32 tensor");
             const int64_t out = e.shape[0], in = e.shape[1] * per;
-            if ((size_t)(out * e.shape[1] * 4) != e.bytes || si->second.shape != std::vector<int64_t>{out, in / group})
-                throw std::runtime_error("quantised " + name + ": shape mismatch (bits/group?)");
-            tmp.resize((size_t)out * in);
-            const uint32_t mask = (1u << bits) - 1u;
-            for (int64_t r = 0; r < out; ++r)
-                for (int64_t c = 0; c < in; ++c) {
-                    uint32_t wv;
-                    std::memcpy(&wv, e.data + 4 * (r * e.shape[1] + c / per), 4);
-                    const float q = (float)((wv >> (bits * (c % per))) & mask);      // LSB-first packing (mlx)
-                    const size_t g = (size_t)(r * (in / group) + c / group);
-                    tmp[(size_t)(r * in + c)] = f32_to_bf16_host(q * elem_f32(si->second, g) + elem_f32(bi->second, g));
-                }
-            int64_t shp[2] = {out, in};
-            set_tensor(name, tmp.data(), QASR_DTYPE_BF16, shp, 2);
+            if ((size_t)(out * e.shape[1] * 4) != e.bytes || in % group != 0)
+                throw std::runtime_error("quantised " + name + ": byte size / group mismatch (bits?)");
+            // scales and biases: 2-D [out, in / group], a float dtype, byte size == numel * element size (untrusted metadata)
+            std::vector<float> wide;
+            auto upload_sb = [&](const std::string& nm, const Entry& t) {
+                if (t.shape != std::vector<int64_t>{out, in / group}) throw std::runtime_error(nm + ": expected [out, in / group]");
+                const size_t numel = (size_t)out * (size_t)(in / group);
+                const size_t el = t.dtype == "F32" ? 4 : (t.dtype == "BF16" || t.dtype == "F16") ? 2 : 0;
+                if (el == 0) throw std::runtime_error(nm + ": scales / biases must be F32, F16 or BF16");
+                if (numel * el != t.bytes) throw std::runtime_error(nm + ": byte size does not match shape");
+                if (t.dtype == "BF16") { set_tensor(nm, t.data, QASR_DTYPE_BF16, t.shape.data(), 2); return; }
+                wide.resize(numel);
+                for (size_t i = 0; i < numel; ++i) wide[i] = elem_f32(t, i);          // f16 -> f32 is exact
+                set_tensor(nm, wide.data(), QASR_DTYPE_F32, t.shape.data(), 2);
+            };
+            if (si->second.dtype != bi->second.dtype) throw std::runtime_error(stem + ": scales and biases differ in dtype");
+            upload_sb(stem + ".scales", si->second);
+            upload_sb(stem + ".biases", bi->second);
+            set_tensor(name, e.data, QASR_DTYPE_U32, e.shape.data(), 2);
         } else {
             upload_float(name, e);
         }

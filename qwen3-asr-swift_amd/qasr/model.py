@@ -66,15 +66,17 @@ class Qwen3ASRModel:
 
     @classmethod
     def from_state_dict(cls, sd, preset="0.6B", device=0, **capacity):
-        """Upload reference-named bf16 torch tensors (qasr.synth) through qasr_set_tensor."""
+        """Upload reference-named torch tensors (qasr.synth) through qasr_set_tensor: bf16 / f32 float tensors, int32
+        tensors holding the uint32 words of MLX-quantised weights (qasr.synth.quantize_state_dict)."""
         import torch
+        codes = {torch.bfloat16: 1, torch.float32: 0, torch.int32: 3}
         m = cls(preset=preset, device=device, **capacity)
         for name, t in sd.items():
             t = t.contiguous()
-            if t.dtype != torch.bfloat16:
-                raise QasrError(f"{name}: expected bf16, got {t.dtype}")
+            if t.dtype not in codes:
+                raise QasrError(f"{name}: expected bf16 / f32 / int32 (uint32 words), got {t.dtype}")
             shape = (C.c_int64 * t.dim())(*t.shape)
-            m._check(m.lib.qasr_set_tensor(m.h, name.encode(), C.c_void_p(t.data_ptr()), 1, shape, t.dim()))
+            m._check(m.lib.qasr_set_tensor(m.h, name.encode(), C.c_void_p(t.data_ptr()), codes[t.dtype], shape, t.dim()))
         m._check(m.lib.qasr_finalize(m.h))
         return m
 

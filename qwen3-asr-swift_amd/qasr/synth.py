@@ -91,3 +91,51 @@ def synth_state_dict(audio_cfg, text_cfg, seed: int = 0, init: str = "hf", dtype
         sd["lm_head.weight"] = (torch.randn(classify_num, t.hidden, generator=g) * std).to(dtype)
         sd["lm_head.bias"] = (torch.randn(classify_num, generator=g) * 0.05).to(dtype)
     return sd
+
+
+QUANT_GROUP = 64
+
+
+def quantize_linear(w, bits, group=QUANT_GROUP):
+    """MLX affine quantisation of one [out, in] weight (mlx `quantize`: per 64-element group of a row, scale and bias from
+    the group's min / max, q in [0, 2^bits)) -> (packed int32 [out, in * bits / 32] holding the uint32 words, LSB-first
+    element order, scales, biases in w's dtype).  This is how a synthetic MLX-4bit / 8bit checkpoint is made for the tests
+    and the W4 / W8 bench legs; the on-disk format is the reference's (Sources/MLXCommon/WeightLoading.swift:48-96)."""
+    dt = w.dtype
+    x = w.to(torch.float32)
+    out, n = x.shape
+    assert n % group == 0 and bits in (4, 8)
+    g = x.reshape(out, n // group, group)
+    n_bins = float((1 << bits) - 1)
+    w_max, w_min = g.max(dim=-1).values, g.min(dim=-1).values
+    mask = w_min.abs() > w_max.abs()
+    scales = torch.clamp((w_max - w_min) / n_bins, min=1e-7)
+    scales = torch.where(mask, scales, -scales)
+    edge = torch.where(mask, w_min, w_max)
+    q0 = torch.round(edge / scales)
+    scales = torch.where(q0 != 0, edge / q0, scales)
+    biases = torch.where(q0 == 0, torch.zeros_like(edge), edge)
+    scales, biases = scales.to(dt), biases.to(dt)
+    q = torch.clamp(torch.round((g - biases.to(torch.float32)[..., None]) / scales.to(torch.float32)[..., None]), 0, n_bins)
+    q = q.reshape(out, n).to(torch.int64)
+    per = 32 // bits
+    q = q.reshape(out, n // per, per)
+    shifts = torch.arange(per, dtype=torch.int64) * bits
+    words = (q << shifts).sum(dim=-1)                       # < 2^32
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    return words.contiguous(), scales.contiguous(), biases.contiguous()
+
+
+def quantize_state_dict(sd, bits, group=QUANT_GROUP):
+    """Float decoder state dict -> the quantised checkpoint layout: every `model.layers.*` Linear and the tied
+    `model.embed_tokens` become {weight: packed uint32 (as int32 bits), scales, biases}; norms and the audio tower stay
+    float (QuantizedTextDecoder.swift:178-199, AudioEncoder is not quantised)."""
+    out = {}
+    for k, v in sd.items():
+        is_lin = k.startswith("model.layers.") and k.endswith("_proj.weight")
+        if is_lin or k == "model.embed_tokens.weight":
+            stem = k[:-len(".weight")]
+            out[k], out[stem + ".scales"], out[stem + ".biases"] = quantize_linear(v, bits, group)
+        else:
+            out[k] = v
+    return out

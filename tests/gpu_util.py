@@ -41,14 +41,16 @@ class Engine:
             self.h = None
 
     def load_state_dict(self, sd):
-        """Upload a reference-named torch state dict (bf16) tensor by tensor, then finalize."""
+        """Upload a reference-named torch state dict tensor by tensor, then finalize: bf16 / f32 float tensors, int32
+        tensors = the uint32 words of MLX-quantised weights."""
         import torch
+        codes = {torch.bfloat16: "bf16", torch.float32: "f32", torch.int32: "u32"}
         for name, t in sd.items():
             t = t.contiguous()
-            assert t.dtype == torch.bfloat16, (name, t.dtype)
+            assert t.dtype in codes, (name, t.dtype)
             shape = (C.c_int64 * t.dim())(*t.shape)
             self.check(self.lib.qasr_set_tensor(self.h, name.encode(), C.c_void_p(t.data_ptr()),
-                                                _lib_dtype("bf16"), shape, t.dim()))
+                                                _lib_dtype(codes[t.dtype]), shape, t.dim()))
         self.check(self.lib.qasr_finalize(self.h))
 
     def encode(self, mel):

@@ -177,45 +177,29 @@ def test_unload_and_footprint(sd):
         m.close()
 
 
-def _mlx_quantize(w, bits, group=64):
-    """Affine group quantisation in the layout the reference's checkpoints use (PreQuantizedEmbedding.swift:
-    22-29): uint32 words holding 32/bits values LSB-first, per-group scale/bias; w ~= q*scale + bias."""
-    w = w.to(torch.float32).numpy()
-    out, inn = w.shape
-    g = w.reshape(out, inn // group, group)
-    lo, hi = g.min(-1), g.max(-1)
-    scale = np.maximum((hi - lo) / (2 ** bits - 1), 1e-8).astype(np.float32)
-    scale = torch.from_numpy(scale).to(torch.bfloat16).to(torch.float32).numpy()
-    bias = torch.from_numpy(lo.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
-    q = np.clip(np.round((g - bias[..., None]) / scale[..., None]), 0, 2 ** bits - 1).astype(np.uint32).reshape(out, inn)
-    per = 32 // bits
-    packed = np.zeros((out, inn // per), dtype=np.uint32)
-    for j in range(per):
-        packed |= q[:, j::per] << np.uint32(bits * j)
-    deq = (q.reshape(out, inn // group, group).astype(np.float32) * scale[..., None] + bias[..., None]).reshape(out, inn)
-    return packed, scale, bias, torch.from_numpy(deq).to(torch.bfloat16)
-
-
-@pytest.mark.parametrize("bits", [4, 8])
-def test_safetensors_and_mlx_quantised_checkpoint(tmp_path, sd, bits):
+@pytest.mark.parametrize("bits,sb_dtype", [(4, torch.bfloat16), (8, torch.bfloat16), (4, torch.float16)])
+def test_safetensors_and_mlx_quantised_checkpoint(tmp_path, sd, bits, sb_dtype):
+    """A sharded safetensors directory in the reference's layout (WeightLoading.swift:235-323): MLX-quantised triplets for
+    every decoder Linear and the tied embedding, mixed on-disk float dtypes for the audio tower.  The loader must hand the
+    engine exactly the tensors `qasr_set_tensor` would: same tokens as an engine built from the same triplets in memory
+    (packed words untouched, bf16 scales kept, f16 scales widened to f32 -- nothing rounded).  Parity of the quantised
+    kernels themselves against the oracle: tests/test_gpu_quant.py."""
     from safetensors.torch import save_file
-    tensors, expect = {}, dict(sd)
-    for name, t in sd.items():
-        quant = name.startswith("model.") and name.endswith("proj.weight") or name == "model.embed_tokens.weight"
-        if quant and t.shape[1] % 64 == 0:
-            packed, scale, bias, deq = _mlx_quantize(t, bits)
-            stem = name[:-len(".weight")]
-            tensors[name] = torch.from_numpy(packed.view(np.int32)).view(torch.int32)
-            tensors[stem + ".scales"] = torch.from_numpy(scale).to(torch.bfloat16)
-            tensors[stem + ".biases"] = torch.from_numpy(bias).to(torch.bfloat16)
-            expect[name] = deq
+    qsd = synth.quantize_state_dict(sd, bits)
+    tensors, expect = {}, {}
+    for name, t in qsd.items():
+        if name.endswith(".scales") or name.endswith(".biases"):
+            tensors[name] = t.to(sb_dtype)
+            expect[name] = t if sb_dtype == torch.bfloat16 else t.to(sb_dtype).to(torch.float32)
         elif name.startswith("audio_tower.") and name.endswith(".bias"):
             tensors[name] = t.to(torch.float16)            # mixed on-disk float dtypes
             expect[name] = t.to(torch.float16).to(torch.bfloat16)
         elif name.endswith("layer_norm.weight"):
             tensors[name] = t.to(torch.float32)
+            expect[name] = t
         else:
             tensors[name] = t
+            expect[name] = t
     keys = sorted(tensors)
     half = len(keys) // 2
     # safetensors has no uint32 in older torch: store as int32 and patch the dtype string in the header
@@ -235,15 +219,54 @@ def test_safetensors_and_mlx_quantised_checkpoint(tmp_path, sd, bits):
     (tmp_path / "vocab.json").write_text(json.dumps({"a": 0, "b": 1, "<asr_text>": 7}))
     (tmp_path / "tokenizer_config.json").write_text(json.dumps({"added_tokens_decoder": {"501": {"content": "<|im_end|>"}}}))
     m = Qwen3ASRModel(preset="tiny", model_dir=str(tmp_path), max_audio_seconds=4, max_new_tokens=16, bits=bits)
-    ref = Qwen3ASRModel.from_state_dict(expect, preset="tiny", max_audio_seconds=4, max_new_tokens=16)
+    ref = Qwen3ASRModel.from_state_dict(expect, preset="tiny", max_audio_seconds=4, max_new_tokens=16, bits=bits)
     try:
         assert m.is_loaded
+        assert m.memory_footprint == ref.memory_footprint          # packed words + scales + biases, not a bf16 expansion
         pcm = synth.synth_waveform(1, 2.0)
         assert m.transcribe_tokens(pcm, max_tokens=10, ignore_eos=True) == ref.transcribe_tokens(pcm, max_tokens=10, ignore_eos=True)
         assert m.detokenize([0, 1, 501, 7, 1, 0]) == "ba"
     finally:
         m.close()
         ref.close()
+
+
+def test_malformed_quantised_checkpoint_is_refused(tmp_path, sd):
+    """Untrusted metadata: scales of the wrong shape / a non-float dtype, and shape entries that overflow, are load errors
+    (QASR_ERR_IO), not out-of-bounds reads."""
+    from safetensors.torch import save_file
+    qsd = synth.quantize_state_dict(sd, 4)
+    stem = "model.layers.0.mlp.up_proj"
+
+    def write(mut):
+        t = {k: v.contiguous() for k, v in qsd.items()}
+        mut(t)
+        path = tmp_path / "model.safetensors"
+        save_file(t, str(path))
+        raw = path.read_bytes()
+        hlen = int.from_bytes(raw[:8], "little")
+        header = json.loads(raw[8:8 + hlen])
+        for k, v in header.items():
+            if k != "__metadata__" and v["dtype"] == "I32" and k.endswith(".weight"):
+                v["dtype"] = "U32"
+        hb = json.dumps(header, separators=(",", ":")).encode()
+        hb += b" " * (hlen - len(hb))
+        path.write_bytes(raw[:8] + hb + raw[8 + hlen:])
+
+    def short_scales(t):
+        t[stem + ".scales"] = t[stem + ".scales"][:, :1].repeat(1, 1)[:-1]
+    def int_biases(t):
+        t[stem + ".biases"] = torch.zeros_like(t[stem + ".biases"], dtype=torch.int16)
+    for mut in (short_scales, int_biases):
+        write(mut)
+        with pytest.raises(Exception, match="qasr_create failed"):
+            Qwen3ASRModel(preset="tiny", model_dir=str(tmp_path), max_audio_seconds=2, max_new_tokens=8, bits=4)
+    # a header whose JSON nests deeper than any checkpoint does
+    p = tmp_path / "model.safetensors"
+    hb = (b"[" * 5000) + (b"]" * 5000)
+    p.write_bytes(len(hb).to_bytes(8, "little") + hb)
+    with pytest.raises(Exception, match="qasr_create failed"):
+        Qwen3ASRModel(preset="tiny", model_dir=str(tmp_path), max_audio_seconds=2, max_new_tokens=8, bits=4)
 
 
 def test_missing_checkpoint_dir():

@@ -1,0 +1,139 @@
+"""MLX 4 / 8-bit quantised text decoder on the device vs the CPU oracle, via the C ABI.
+
+The oracle (oracle/quant.py, oracle/decoder.py: Weights.linear / embed_rows) restates what the reference's backend does
+with a `QuantizedLinear` / `PreQuantizedEmbedding`: embedding rows and the prompt pass use bf16(scale * q + bias), a decode
+step (one row of x per sequence) multiplies by scale * q + bias in f32 without rounding it.  The device keeps the packed
+words in HBM and computes the decode-step form sum_g scale_g (sum q x) + bias_g (sum x) on the matrix cores
+(csrc/dec_quant.hip); the prompt pass runs its bf16 GEMMs on bf16(scale * q + bias) copies.
+
+Tolerances: those of the float decoder tests -- logits are bf16 values, max |d| within 6 bf16 ulps of the largest |logit|
+(0.06 on the tiny geometry) and relative L2 < 3e-2 (1.5e-2 tiny), tokens teacher-forced within the same margin.
+"""
+import dataclasses
+import numpy as np
+import pytest
+import torch
+from oracle import config as C, decoder, pipeline, precision as P
+from qasr import synth
+import gpu_util
+
+pytestmark = pytest.mark.gpu
+A, T, TOK = C.AUDIO_TINY, C.TEXT_TINY, C.TOKENS_TINY
+
+
+def _ulp_tol(ref, ulps=6.0):
+    m = float(np.abs(ref).max())
+    return ulps * 2.0 ** (np.floor(np.log2(max(m, 1e-3))) - 7)
+
+
+def _check(got, ref, rel_bar, what):
+    d, rel = np.abs(got - ref).max(), np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    print(f"{what}: max|d| {d:.4f} ({d / _ulp_tol(ref, 1.0):.1f} ulps) rel-L2 {rel:.2e}")
+    assert d <= _ulp_tol(ref) and rel < rel_bar, (what, d, rel)
+    assert ref[int(got.argmax())] >= ref.max() - _ulp_tol(ref)
+
+
+@pytest.mark.parametrize("bits,sb_f32", [(4, False), (8, False), (4, True)], ids=["w4", "w8", "w4-f32scales"])
+def test_tiny_geometry_generic_kernels(bits, sb_f32):
+    """hidden 64 / inter 128: no tuned instantiation exists, every quantised product takes the generic kernel and the
+    generic LM head (one argmax partial per row)."""
+    sd = synth.synth_state_dict(A, T, seed=3, init="stress")
+    qsd = synth.quantize_state_dict(sd, bits)
+    if sb_f32:
+        qsd = {k: (v.to(torch.float32) if k.endswith((".scales", ".biases")) else v) for k, v in qsd.items()}
+    eng = gpu_util.Engine("tiny", max_audio_seconds=10, max_new_tokens=24, bits=bits)
+    try:
+        eng.load_state_dict(qsd)
+        W = decoder.Weights(qsd)
+        emb = P.bf16_round(torch.randn(33, T.hidden, generator=torch.Generator().manual_seed(1)) * 0.5)
+        with torch.no_grad():
+            toks, logits = decoder.greedy(emb, W, T, P.DEVICE, TOK, max_tokens=10, ignore_eos=True, return_logits=True)
+        _check(eng.prefill_logits(emb.numpy()), logits[0].numpy(), 1.5e-2, "prompt pass")
+        got = eng.decode_forced(toks[:-1])
+        for i in range(len(toks) - 1):
+            _check(got[i], logits[i + 1].numpy(), 1.5e-2, f"step {i}")
+        # whole path, batch of ragged clips, teacher-forced; each clip alone gives the same tokens
+        model = pipeline.OracleModel(qsd, A, T, TOK, P.DEVICE)
+        clips = [synth.synth_waveform(0, 2.5), synth.synth_waveform(1, 1.0), synth.synth_waveform(2, 0.4)]
+        out = eng.transcribe_batch(clips, max_tokens=8, ignore_eos=True)
+        with torch.no_grad():
+            for pcm, tk in zip(clips, out):
+                e = model.encode(model.mel(pcm))
+                lg, st, _ = decoder.prefill(e, model.W, T, P.DEVICE, TOK)
+                for i, t in enumerate(tk):
+                    assert lg[t] >= lg.max() - 0.06, (i, t)
+                    if i + 1 < len(tk):
+                        lg = decoder.decode_step(t, model.W, T, st, P.DEVICE)
+        for pcm, tk in zip(clips, out):
+            assert eng.transcribe_batch([pcm], max_tokens=8, ignore_eos=True)[0] == tk
+    finally:
+        eng.close()
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    return synth.synth_state_dict(C.AUDIO_SMALL, dataclasses.replace(C.TEXT_SMALL, layers=3), seed=0, init="stress")
+
+
+@pytest.mark.parametrize("bits,sb_f32", [(4, False), (8, False), (8, True)], ids=["w4", "w8", "w8-f32scales"])
+def test_full_width_tuned_kernels(full_sd, bits, sb_f32):
+    """Qwen3-ASR-0.6B widths (hidden 1024, inter 3072, 16/8 heads x 128, vocab 151 936) with 3 decoder layers so the CPU
+    oracle stays affordable: the K = 1024 / 2048 / 3072 tuned quantised GEMVs, the persistent quantised LM head, the
+    quantised embedding gather, at 1 and 32 batch rows."""
+    t = dataclasses.replace(C.TEXT_SMALL, layers=3)
+    qsd = synth.quantize_state_dict(full_sd, bits)
+    if sb_f32:
+        qsd = {k: (v.to(torch.float32) if k.endswith((".scales", ".biases")) else v) for k, v in qsd.items()}
+    eng = gpu_util.Engine("0.6B", max_batch=32, max_audio_seconds=6, max_new_tokens=16, dec_layers=3, bits=bits)
+    try:
+        eng.load_state_dict(qsd)
+        W = decoder.Weights(qsd)
+        emb = P.bf16_round(torch.randn(65, t.hidden, generator=torch.Generator().manual_seed(2)) * 0.5)
+        with torch.no_grad():
+            toks, logits = decoder.greedy(emb, W, t, P.REFERENCE, C.TOKENS, max_tokens=7, ignore_eos=True, return_logits=True)
+        _check(eng.prefill_logits(emb.numpy()), logits[0].numpy(), 3e-2, "prompt pass T=81")
+        got = eng.decode_forced(toks[:-1])
+        for i in range(len(toks) - 1):
+            _check(got[i], logits[i + 1].numpy(), 3e-2, f"step {i}")
+        # 32 rows (two batch tiles) == every clip alone, deterministic
+        clips = [synth.synth_waveform(k, 1.0 + 0.11 * (k % 5)) for k in range(32)]
+        a = eng.transcribe_batch(clips, max_tokens=5, ignore_eos=True)
+        assert eng.transcribe_batch(clips, max_tokens=5, ignore_eos=True) == a
+        for k in (0, 15, 16, 31):
+            assert eng.transcribe_batch([clips[k]], max_tokens=5, ignore_eos=True)[0] == a[k]
+        assert eng.transcribe_batch(clips[3:20], max_tokens=5, ignore_eos=True) == a[3:20]
+    finally:
+        eng.close()
+
+
+def test_quantised_differs_from_its_bf16_expansion(full_sd):
+    """Why the packed kernels exist: a decode step on bf16(scale * q + bias) weights (what round 1 did at load) is NOT
+    what the reference computes.  On the same 4-bit triplets the two give measurably different logits; the device
+    follows the f32-dequantised form to within the usual tolerance while the bf16 expansion sits further away."""
+    t = dataclasses.replace(C.TEXT_SMALL, layers=3)
+    qsd = synth.quantize_state_dict(full_sd, 4)
+    W = decoder.Weights(qsd)
+    fsd = dict(full_sd)
+    for k in list(qsd):
+        if k.endswith(".scales"):
+            stem = k[:-len(".scales")]
+            fsd[stem + ".weight"] = W._dequant(stem, rounded=True).to(torch.bfloat16)
+    emb = P.bf16_round(torch.randn(40, t.hidden, generator=torch.Generator().manual_seed(5)) * 0.5)
+    with torch.no_grad():
+        lq, sq, _ = decoder.prefill(emb, W, t, P.REFERENCE, C.TOKENS)
+        tok = int(lq.argmax())
+        step_q = decoder.decode_step(tok, W, t, sq, P.REFERENCE).numpy()
+        lf, sf, _ = decoder.prefill(emb, decoder.Weights(fsd), t, P.REFERENCE, C.TOKENS)
+        step_f = decoder.decode_step(tok, decoder.Weights(fsd), t, sf, P.REFERENCE).numpy()
+    gap = np.linalg.norm(step_q - step_f) / np.linalg.norm(step_q)
+    eng = gpu_util.Engine("0.6B", max_batch=1, max_audio_seconds=6, max_new_tokens=16, dec_layers=3, bits=4)
+    try:
+        eng.load_state_dict(qsd)
+        eng.prefill_logits(emb.numpy())
+        got = eng.decode_forced([tok])[0]
+    finally:
+        eng.close()
+    d_q = np.linalg.norm(got - step_q) / np.linalg.norm(step_q)
+    d_f = np.linalg.norm(got - step_f) / np.linalg.norm(step_f)
+    print(f"oracle exact-vs-bf16-expansion gap {gap:.2e}; device vs exact {d_q:.2e}, device vs expansion {d_f:.2e}")
+    assert d_q < 3e-2
