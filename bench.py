@@ -7,8 +7,9 @@ waveforms + seeded random weights of the real architecture (no checkpoint / data
 
 A "step" = one pass of the whole hot path (log-mel -> audio encoder -> prompt pass -> N_dec greedy
 decode steps -> token ids on host -> RCCL all_gather of the [B, 449] int32 token block) over one batch
-that is already resident in HBM (qasr_batch_begin uploads it before the timed region; the
-PCIe-inclusive rate is reported separately and never as `value`).  Decode length is forced to
+whose PCM sits in host memory when the pass starts (qasr_batch_begin: pinned staging + H2D + planning, all
+inside the timed region, SURVEY.md section 8d "pcm on host -> token ids on host"); `resident_value` is
+the same pass with the batch already in HBM.  Decode length is forced to
 N_dec = 128 tokens per clip (EOS ignored) so the work is deterministic -- SURVEY.md section 8(d).
 
 Launch:  python bench.py [--gpus 1]            or, for N > 1 (one rank per GPU, RCCL):
@@ -32,6 +33,7 @@ import torch                # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from qasr import _lib, synth          # noqa: E402
+from qasr import dist as qdist        # noqa: E402
 from qasr.model import Qwen3ASRModel  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6300 GB/s achievable)
@@ -74,7 +76,7 @@ def cpu_baseline(sd, pcm, n_dec):
 MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
 
 
-def stage_roofline(B, seconds, n_dec, stage_ms, steps):
+def stage_roofline(B, seconds, n_dec, stage_ms, steps, bits=16):
     """Per-stage achieved rate of the last timed pass against the bound SURVEY.md section 8(d) names for it, from the
     survey's algorithmic work per 30 s clip (scaled linearly with the clip length) and the HIP-event stage times."""
     k = seconds / 30.0
@@ -84,7 +86,9 @@ def stage_roofline(B, seconds, n_dec, stage_ms, steps):
     enc_f = 270.7e9 * k * B
     pre_f = 376.8e9 * k * B                          # (mildly superlinear in T through attention; 30 s is the quoted case)
     # decode: weights once per step for the whole batch + every row's K/V rows; the first token comes from the prompt pass
-    dec_b = steps * 1.192e9 + B * 114688.0 * sum(prompt + i for i in range(steps))
+    # weights: 596.0 M parameters x 2 B (bf16) or bits / 8 + (scale + bias, bf16) / 64 per parameter (MLX group 64)
+    w_b = 1.192e9 if bits == 16 else 596.0e6 * (bits / 8.0 + 4.0 / 64.0)
+    dec_b = steps * w_b + B * 114688.0 * sum(prompt + i for i in range(steps))
     out = {"mel": {"bound": "hbm", "achieved": round(mel_b / stage_ms[0] / 1e6, 1), "unit": "GB/s", "frac": round(mel_b / stage_ms[0] / 1e6 / HBM_PEAK_GBS, 4)},
            "encoder": {"bound": "mfma", "achieved": round(enc_f / stage_ms[1] / 1e9, 1), "unit": "TFLOP/s",
                        "frac": round(enc_f / stage_ms[1] / 1e9 / MFMA_PEAK_TFLOPS, 4)},
@@ -97,6 +101,23 @@ def stage_roofline(B, seconds, n_dec, stage_ms, steps):
     return out
 
 
+def kernel_source_stamp():
+    """sha256 (first 16 hex) of the decode-kernel sources: a PMC traffic file is only quoted for the kernels it was
+    measured on (profiles/*_pmc_traffic.json carries the stamp of the build it was taken from)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("dec_kernels.hip", "dec_kernels.h", "dec_epilogue.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "qwen3-asr-swift_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run_leg(model, clips, n_dec, steps, warmup, world, gathered, inclusive):
+    """K timed passes (qasr.dist.timed_passes: barrier + synchronize on both sides, MAX over ranks)."""
+    dt, lens = qdist.timed_passes(model, clips, n_dec, steps, warmup, inclusive, gathered)
+    assert (lens == n_dec).all(), lens
+    return dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +126,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--decode-tokens", type=int, default=128)
+    ap.add_argument("--bits", type=int, default=16, choices=[16, 8, 4],
+                    help="weights of the HEADLINE engine: 16 = bf16 (BASELINE's config), 4 / 8 = MLX-quantised decoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the b=1 / b=8 and MLX-4bit legs (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,55 +148,38 @@ def main():
     log(f"rank {rank}/{world}: generating synthetic weights ...")
     from qasr import config as QC
     sd = synth.synth_state_dict(QC.AUDIO_SMALL, QC.TEXT_SMALL, seed=0, init="hf")
-    model = Qwen3ASRModel.from_state_dict(sd, preset="0.6B", device=local_rank, max_batch=B,
-                                          max_audio_seconds=int(np.ceil(args.seconds)), max_new_tokens=448)
+    cap = dict(device=local_rank, max_batch=B, max_audio_seconds=int(np.ceil(args.seconds)), max_new_tokens=448)
+
+    def build(bits):
+        if bits == 16:
+            return Qwen3ASRModel.from_state_dict(sd, preset="0.6B", bits=16, **cap)
+        return Qwen3ASRModel.from_state_dict(synth.quantize_state_dict(sd, bits), preset="0.6B", bits=bits, **cap)
+
+    model = build(args.bits)
     # weak scaling: every rank gets its own B clips (clip ids rank*B ...), no data-path collective
-    clips = [synth.synth_waveform(rank * B + k, args.seconds) for k in range(B)]
+    clips = [synth.synth_waveform(k, args.seconds) for k in qdist.weak_scaling_clip_ids(rank, B)]
     stride = model.cfg.max_new_tokens + 1
-
-    log("weights resident; uploading batch ...")
-    t0 = time.perf_counter()
-    model.batch_begin(clips, max_tokens=n_dec, ignore_eos=True)
-    model.batch_sync()
-    h2d_s = time.perf_counter() - t0
-
     gathered = torch.empty((world * B, stride), dtype=torch.int32, device="cuda")
 
-    def step():
-        model.batch_rewind()
-        model.batch_run()
-        toks, lens = model.batch_tokens()                     # D2H, syncs the engine stream
-        block = torch.from_numpy(toks).cuda(non_blocking=True)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, block)      # RCCL over xGMI: [B, 449] int32 per rank
-        else:
-            gathered.copy_(block)
-        return lens
-
-    for _ in range(args.warmup):
-        step()
-    log("warmup done; timing ...")
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lens = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert (lens == n_dec).all(), lens
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    log("weights resident; timing host pcm -> host tokens ...")
+    dt = run_leg(model, clips, n_dec, args.steps, args.warmup, world, gathered, inclusive=True)
     log(f"timed {args.steps} steps in {dt * 1e3:.1f} ms")
     stage_ms, steps_done = model.batch_timings()
+    # the same passes with the batch already resident in HBM (no staging copy / H2D / planning in the timed region)
+    dt_res = run_leg(model, clips, n_dec, args.steps, 1, world, gathered, inclusive=False)
     probe = {name: model.kernel_probe(which, 20) for which, name in ((0, "layer_gemv"), (1, "decode_attn"), (2, "lm_head"))}
+
+    extras = {}
+    if world == 1 and not args.no_extras:
+        # BASELINE's metric is quoted at batch {1, 8, 32}: the smaller batches on the same engine, same timed region
+        for b in (1, 8):
+            if b < B:
+                d = run_leg(model, clips[:b], n_dec, 3, 1, 1, None, inclusive=True)
+                ms, _ = model.batch_timings()
+                extras[f"b{b}"] = {"value": round(b * args.seconds * 3 / d, 1), "ms_per_step": round(d / 3 * 1e3, 3),
+                                   "stage_ms": {"mel": round(ms[0], 3), "encoder": round(ms[1], 3), "prompt_pass": round(ms[2], 3),
+                                                "decode": round(ms[3], 3)}}
+                log(f"b={b}: {extras[f'b{b}']}")
 
     if rank == 0:
         audio_s = world * B * args.seconds * args.steps
@@ -181,13 +188,19 @@ def main():
         dom_ms, dom_bytes = probe["decode_attn"]
         traffic, traffic_note = None, None
         import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-        if pmc_files:                      # measured in separate rocprofv3 --pmc passes (see the file's "source")
-            pmc = json.load(open(pmc_files[-1]))
+        stamp = kernel_source_stamp()
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            pmc = json.load(open(f))
+            if pmc.get("kernel_source_stamp") != stamp:
+                continue                   # measured on other kernel sources: stale, not quoted
             traffic = pmc.get("decode_attention_bytes")
             alg = pmc.get("decode_attention_algorithmic_bytes_at_that_context")
-            traffic_note = (f"profiles/{os.path.basename(pmc_files[-1])}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate "
-                            f"--pmc passes of a 16-token run; algorithmic bytes at that run's mean context: {alg}")
+            traffic_note = (f"profiles/{os.path.basename(f)} (kernel sources {stamp}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
+                            f"separate --pmc passes of a 16-token run; algorithmic bytes at that run's mean context: {alg}")
+            break
+        if traffic is None:
+            traffic_note = f"no PMC file under profiles/ matches the current kernel sources ({stamp}); not quoted"
+        wname = "bf16" if args.bits == 16 else f"MLX {args.bits}-bit decoder (packed in HBM), bf16 activations"
         out = {
             "metric": "audio-seconds/sec (RTF^-1) Qwen3-ASR-0.6B, 30 s@16 kHz, b=32 per GPU",
             "value": round(audio_s / dt, 1),
@@ -196,17 +209,19 @@ def main():
             "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Qwen3-ASR-0.6B geometry, {B} clips x {args.seconds:.0f} s per GPU "
-                                   f"(BASELINE metric's b=32; x8 GPUs = configs[2]), mel+encoder+prompt pass+"
-                                   f"{n_dec} forced greedy tokens, tokens gathered over RCCL",
-                       "clips_per_gpu": B, "clip_seconds": args.seconds, "decode_tokens": n_dec,
+            "config": {"workload": f"Qwen3-ASR-0.6B geometry ({wname}), {B} clips x {args.seconds:.0f} s per GPU "
+                                   f"(BASELINE metric's b=32; x8 GPUs = configs[2]), timed region = pcm in host memory -> "
+                                   f"mel + encoder + prompt pass + {n_dec} forced greedy tokens -> token ids in host memory, "
+                                   f"tokens gathered over RCCL",
+                       "clips_per_gpu": B, "clip_seconds": args.seconds, "decode_tokens": n_dec, "weights": wname,
                        "sharding": f"dp{world} (independent clips, weights replicated)"},
             "rtf": round(dt / audio_s, 7),
             "stage_ms": {"mel": round(stage_ms[0], 3), "encoder": round(stage_ms[1], 3),
                          "prompt_pass": round(stage_ms[2], 3), "decode": round(stage_ms[3], 3),
                          "decode_steps": steps_done},
-            "pcie_inclusive_value": round(world * B * args.seconds / (ms_step / 1e3 + h2d_s), 1),
-            "stage_roofline": stage_roofline(B, args.seconds, n_dec, stage_ms, steps_done),
+            "resident_value": round(audio_s / dt_res, 1),
+            "resident_note": "same passes with the batch already in HBM (qasr_batch_rewind): no staging copy / H2D / planning timed",
+            "stage_roofline": stage_roofline(B, args.seconds, n_dec, stage_ms, steps_done, args.bits),
             "roofline": {"bound": "hbm",
                          "kernel": "decode_attention_mfma_kernel (one launch = one decoder layer's attention for all batch rows: "
                                    "K and V rows of every row's context are streamed once)",
@@ -220,13 +235,32 @@ def main():
                          "other": {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)}
                                    for k, v in probe.items()}},
         }
+        if extras:
+            out["batches"] = extras
+    model.close()
+    if rank == 0 and world == 1 and not args.no_extras and args.bits == 16:
+        # the reference's shipped checkpoints are MLX 4-bit: same workload on a synthetic 4-bit checkpoint,
+        # packed weights in HBM (csrc/dec_quant.hip).  Reported beside the bf16 headline, never as `value`.
+        log("building the MLX-4bit engine ...")
+        m4 = build(4)
+        d4 = run_leg(m4, clips, n_dec, args.steps, 1, 1, None, inclusive=True)
+        ms4, st4 = m4.batch_timings()
+        p4 = {name: m4.kernel_probe(which, 20) for which, name in ((0, "layer_gemv"), (2, "lm_head"))}
+        out["mlx_4bit"] = {"value": round(B * args.seconds * args.steps / d4, 1), "ms_per_step": round(d4 / args.steps * 1e3, 3),
+                           "stage_ms": {"mel": round(ms4[0], 3), "encoder": round(ms4[1], 3), "prompt_pass": round(ms4[2], 3),
+                                        "decode": round(ms4[3], 3), "decode_steps": st4},
+                           "stage_roofline_decode": stage_roofline(B, args.seconds, n_dec, ms4, st4, 4).get("decode"),
+                           "kernels": {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)} for k, v in p4.items()},
+                           "note": "synthetic weights quantised with mlx's affine scheme (group 64); decode-step products in the "
+                                   "reference's f32-dequantised form, prompt pass on bf16(scale*q+bias) like its many-row kernel"}
+        m4.close()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, clips[0], n_dec)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    model.close()
 
 
 if __name__ == "__main__":

@@ -738,13 +738,15 @@ void Engine::batch_begin(const float* const* pcm, const size_t* n, size_t B, con
     opt_temperature_ = opt ? opt->temperature : 0.0f;
     opt_seed_ = opt ? opt->seed : 0;
     slow_path_ = !(opt_rep_penalty_ == 1.0f && opt_ngram_ == 0 && opt_temperature_ == 0.0f);
+    // the pinned staging buffers (pcm, plans) are reused per batch: the previous batch's copies must have drained.  No wait
+    // at the end: the uploads run under the host-side planning and the kernels of qasr_batch_run queue behind them.
+    QASR_HIP(hipStreamSynchronize(stream_));
     upload_pcm(pcm, n, B);
     plan_encoder();
     std::vector<int> n_audio;
     for (auto& c : clips_) n_audio.push_back(c.n_tokens);
     plan_prefill(opt, n_audio);
     reset_greedy_state(max_tokens, opt && opt->ignore_eos);
-    QASR_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::batch_run() {

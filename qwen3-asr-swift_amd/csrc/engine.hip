@@ -2,6 +2,7 @@
 #include "engine.h"
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 namespace qasr {
 
@@ -137,7 +138,6 @@ void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
         if (n[b] == 0) throw std::invalid_argument("empty clip");
         if ((long)n[b] > max_samples_) throw std::length_error("clip longer than max_audio_seconds");
         ClipPlan c = plan_clip(cfg_, (long)n[b], 0);
-        std::memcpy(h_pcm_.as<float>() + off, pcm[b], n[b] * sizeof(float));
         h_off[b] = off;
         h_ns[b] = (int)n[b];
         h_fo[b] = frame_off;
@@ -147,6 +147,21 @@ void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
         clips_.push_back(std::move(c));
     }
     batch_ = (int)B;
+    // caller memory (pageable) -> pinned staging: 61 MB at 32 x 30 s, ~10 ms on one core, so the clips are spread over a few
+    // threads (each thread owns whole clips; the staging buffer is private to this engine)
+    {
+        const long total = off;
+        const int nthr = total > (4L << 20) ? (int)std::min<size_t>(B, 8) : 1;
+        auto copy_range = [&](size_t b0, size_t b1) {
+            for (size_t b = b0; b < b1; ++b) std::memcpy(h_pcm_.as<float>() + h_off[b], pcm[b], n[b] * sizeof(float));
+        };
+        if (nthr <= 1) copy_range(0, B);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; ++t) pool.emplace_back(copy_range, B * t / nthr, B * (t + 1) / nthr);
+            for (auto& th : pool) th.join();
+        }
+    }
     QASR_HIP(hipMemcpyAsync(d_pcm_.p, h_pcm_.p, off * sizeof(float), hipMemcpyHostToDevice, stream_));
     size_t meta_bytes = B * (sizeof(long) + 2 * sizeof(int));
     QASR_HIP(hipMemcpyAsync(d_meta_.p, h_meta_.p, meta_bytes, hipMemcpyHostToDevice, stream_));

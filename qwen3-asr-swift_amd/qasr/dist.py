@@ -58,3 +58,65 @@ def transcribe_sharded(model, clips, device=None, **opt):
             lens[i] = len(t)
     all_t, all_l = gather_tokens(toks, lens, len(clips), device)
     return [all_t[i, :all_l[i]].tolist() for i in range(len(clips))]
+
+
+def weak_scaling_clip_ids(rank, clips_per_rank):
+    """bench.py's weak-scaling assignment: rank r owns synthetic clips r * B .. r * B + B - 1 (no two ranks share a clip)."""
+    return list(range(rank * clips_per_rank, (rank + 1) * clips_per_rank))
+
+
+def _device_sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def timed_passes(model, clips, n_dec, steps, warmup, inclusive, gathered=None):
+    """bench.py's timed region: `warmup` untimed + `steps` timed passes of the hot path over this rank's clips, bracketed
+    by barrier + device synchronisation on both sides, MAX over ranks of the elapsed wall time.
+
+    inclusive: every pass starts from the caller's host buffers (qasr_batch_begin: pinned staging + H2D + planning) and
+    ends with the token ids on the host -- SURVEY.md section 8(d)'s timed region; otherwise the batch stays resident in HBM
+    and qasr_batch_rewind re-arms it (the kernel-only figure).  gathered: [world * B, S] int32 tensor on the collective's
+    device; every pass ends with the all_gather of this rank's [B, S] token block into it (the only exchange of the path).
+    -> (seconds, lens of the last pass)."""
+    import time
+    world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def one_pass():
+        if inclusive:
+            model.batch_begin(clips, max_tokens=n_dec, ignore_eos=True)
+        else:
+            model.batch_rewind()
+        model.batch_run()
+        toks, lens = model.batch_tokens()                     # D2H, waits for the engine stream
+        if gathered is not None:
+            block = torch.from_numpy(toks).to(gathered.device, non_blocking=True)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, block)  # RCCL over xGMI (gloo in the CPU tests): [B, S] int32 per rank
+            else:
+                gathered.copy_(block)
+        return lens
+
+    if not inclusive:
+        model.batch_begin(clips, max_tokens=n_dec, ignore_eos=True)
+        model.batch_sync()
+    for _ in range(warmup):
+        one_pass()
+    _device_sync()
+    if world > 1:
+        dist.barrier()
+    _device_sync()
+    t0 = time.perf_counter()
+    lens = None
+    for _ in range(steps):
+        lens = one_pass()
+    _device_sync()
+    if world > 1:
+        dist.barrier()
+    _device_sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=gathered.device if gathered is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, lens

@@ -38,10 +38,12 @@ def pick(sub):
     return None, 0
 att, n_att = pick("decode_attention")
 lm, _ = pick("lm_head_kernel")
+sys.path.insert(0, root)
+import bench                                    # kernel_source_stamp(): the traffic figure is tied to the kernels it was measured on
 gemv = sum(r[4] * r[1] for r in rows if "decode_gemv2_kernel" in r[0])
 n_layers_steps = n_att
-out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 --decode-tokens 16 "
-                 "--no-cpu-baseline`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
+out = {"kernel_source_stamp": bench.kernel_source_stamp(), "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 --decode-tokens 16 "
+                 "--no-cpu-baseline --no-extras`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
        "decode_attention_bytes": att, "decode_attention_launches": n_att,
        "layer_gemv_group_bytes": gemv / n_att if n_att else None, "lm_head_bytes": lm,
        # 16-token run, 32 rows x 30 s: contexts 406 .. 406+14 over the 15 decode steps -> mean 413; K+V rows of 8 kv heads x 128 x 2 B

@@ -68,3 +68,28 @@ def test_sharded_transcribe_world2(n_clips):
     clips = [np.array([0.001 * (k + 1), k], dtype=np.float32) for k in range(n_clips)]
     expect = _FakeModel().transcribe_batch(clips)
     assert results[0] == expect and results[1] == expect
+
+
+def test_bench_sharding_path_under_torchrun(tmp_path):
+    """bench.py's N > 1 path, launched the way the driver launches it (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 ...`), 2 ranks over gloo with a stand-in engine: rank-local clip ids are
+    disjoint and contiguous, every rank's [B, S] token block lands at its rank offset of the gathered tensor on BOTH
+    ranks, the reported time is the MAX over ranks (the slow rank's), warm-up passes are not timed."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, OUT_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_bench_driver.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    assert [x["ids"] for x in res] == [[0, 1, 2], [3, 4, 5]]
+    expect = [[1000 * k + j for j in range(5)] + [-1] * 4 for k in range(6)]
+    for x in res:
+        assert x["world"] == 2 and x["gathered"] == expect and x["lens"] == [5, 5, 5]
+        assert x["begun"] == 3 + 1 and x["ran"] == 3 + 1            # 1 warm-up + 2 timed inclusive passes, then 1 resident
+        assert x["dt"] >= 2 * 0.20 and x["dt"] < 2 * 0.20 + 0.5       # two passes of the SLOW rank, warm-up excluded
+    assert abs(res[0]["dt"] - res[1]["dt"]) < 1e-9                    # MAX-reduced: identical on both ranks
+    assert abs(res[0]["dt_res"] - res[1]["dt_res"]) < 1e-9 and res[0]["dt_res"] >= 0.20
