@@ -57,6 +57,31 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B frag
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
 
+// Cross-lane sums on the DPP path (v_add_f32 with a lane-permuting source operand, a few cycles) instead of __shfl_xor,
+// which hipcc lowers to ds_bpermute_b32: an LDS round trip (~100 cycles) per step, each behind its own s_waitcnt.
+//   quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E: sums of 4;  row_half_mirror 0x141: lane i <- 7 - i, completes 8;
+//   row_mirror 0x140: lane i <- 15 - i, completes 16.  Every lane of the aligned group ends with the group's sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_sum8(float p) {
+    p += dpp_mov_f32<0xB1>(p);
+    p += dpp_mov_f32<0x4E>(p);
+    p += dpp_mov_f32<0x141>(p);
+    return p;
+}
+// sum over aligned groups of N adjacent lanes (N = 8, 16, 32 or 64), result on every lane of the group
+template <int N>
+__device__ __forceinline__ float lane_sum(float p) {
+    static_assert(N == 8 || N == 16 || N == 32 || N == 64, "group size");
+    p = lane_sum8(p);
+    if constexpr (N >= 16) p += dpp_mov_f32<0x140>(p);
+    if constexpr (N >= 32) p += __shfl_xor(p, 16, 64);
+    if constexpr (N >= 64) p += __shfl_xor(p, 32, 64);
+    return p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

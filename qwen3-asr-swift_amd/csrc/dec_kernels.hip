@@ -896,8 +896,11 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
             }
+            if constexpr (TPR >= 8) ss = lane_sum<(TPR >= 8 ? TPR : 8)>(ss);
+            else {
 #pragma unroll
-            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+                for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            }
             const float inv = rsqrtf(ss / (float)K + a2.eps);
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
@@ -1174,8 +1177,11 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
             }
+            if constexpr (TPR >= 8) ss = lane_sum<(TPR >= 8 ? TPR : 8)>(ss);
+            else {
 #pragma unroll
-            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+                for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            }
             const float inv = rsqrtf(ss / (float)K + a.eps);
             char* xrow = s_x + (size_t)r * XSTRIDE + scol * 16;
 #pragma unroll

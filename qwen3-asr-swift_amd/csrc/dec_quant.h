@@ -13,8 +13,9 @@
 //
 // HBM images built once by qasr_finalize (quant_pack_launch):
 //   q image   uint32, fragment-major: block (16-row tile, BLK columns) = 64 lanes x 16 bytes, lane l = (row l & 15,
-//             k offset 8 (l >> 4)); BLK = 128 columns (4 bit: word i of the lane's uint4 = k-step i of the block) or
-//             64 columns (8 bit: words 2i, 2i+1 = k-step i).  One wave instruction reads 1 KiB contiguous.
+//             k offset 8 (l >> 4)); BLK = 128 columns (4 bit: word i of the lane's uint4 = k-step i of the block, its
+//             nibbles re-ordered to e0 e2 e4 e6 e1 e3 e5 e7 so that a shift + and-or yields a packed bf16 pair -- see
+//             frag_q4) or 64 columns (8 bit: words 2i, 2i+1 = k-step i).  One wave instruction reads 1 KiB contiguous.
 //   sb image  [tile][scales | biases][row 16][group G] in the checkpoint's dtype (bf16) or f32 (f16 / f32 checkpoints):
 //             a lane reads the G values of its row as 16-byte loads.
 #pragma once

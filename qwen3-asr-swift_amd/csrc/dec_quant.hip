@@ -23,14 +23,25 @@ __device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {
 template <int B>
 __device__ __forceinline__ float ubyte_f32(unsigned w) { return (float)((w >> (8 * B)) & 0xFFu); }      // v_cvt_f32_ubyteB
 
+// 4 bit.  The q image stores a k-step's 8 elements of a lane in the nibble order (e0 e2 e4 e6 | e1 e3 e5 e7): element
+// pair (2k, 2k+1) sits in nibbles k and k + 4 (quant_pack_q_kernel).  A nibble placed in the top four mantissa bits of a
+// bf16 with exponent 2^4 is the bf16 value 16 + q, exactly: bits 0x4180 | q << 3.  So one shift and one and-or give a
+// packed pair, 8 vector instructions per fragment instead of 20 for the convert route, and the kernels multiply by
+// (16 + q): sum (16 + q) x = sum q x + 16 sum x, folded into the bias term (bias' = bias - 16 scale, Q4_OFFSET).
+constexpr float Q4_OFFSET = 16.0f;
 __device__ __forceinline__ mfma_bf16x8 frag_q4(unsigned w) {
-    const unsigned ev = w & 0x0F0F0F0Fu, od = (w >> 4) & 0x0F0F0F0Fu;      // bytes: e0 e2 e4 e6 | e1 e3 e5 e7
     uint4 o;
-    o.x = pack_hi16(ubyte_f32<0>(ev), ubyte_f32<0>(od));
-    o.y = pack_hi16(ubyte_f32<1>(ev), ubyte_f32<1>(od));
-    o.z = pack_hi16(ubyte_f32<2>(ev), ubyte_f32<2>(od));
-    o.w = pack_hi16(ubyte_f32<3>(ev), ubyte_f32<3>(od));
+    o.x = ((w << 3) & 0x00780078u) | 0x41804180u;
+    o.y = ((w >> 1) & 0x00780078u) | 0x41804180u;
+    o.z = ((w >> 5) & 0x00780078u) | 0x41804180u;
+    o.w = ((w >> 9) & 0x00780078u) | 0x41804180u;
     return __builtin_bit_cast(mfma_bf16x8, o);
+}
+// bias of a group as the kernels use it: the 4-bit fragments carry 16 + q
+template <int BITS>
+__device__ __forceinline__ float eff_bias(float scale, float bias) {
+    if constexpr (BITS == 4) return fmaf(-Q4_OFFSET, scale, bias);
+    else return bias;
 }
 
 __device__ __forceinline__ mfma_bf16x8 frag_q8(unsigned w0, unsigned w1) {      // w0 = elements 0..3, w1 = 4..7
@@ -42,12 +53,25 @@ __device__ __forceinline__ mfma_bf16x8 frag_q8(unsigned w0, unsigned w1) {      
     return __builtin_bit_cast(mfma_bf16x8, o);
 }
 
+// word i of a 16-byte register block; i is a compile-time constant after unrolling (never an address computation:
+// indexing a register array through a pointer cast sends it to scratch)
+__device__ __forceinline__ unsigned u4_word(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
 // k-step `ks` (0 .. BLK/32 - 1) of a lane's 16-byte block
 template <int BITS>
 __device__ __forceinline__ mfma_bf16x8 frag_of(const uint4& blk, int ks) {
-    const unsigned w[4] = {blk.x, blk.y, blk.z, blk.w};
-    if constexpr (BITS == 4) return frag_q4(w[ks]);
-    else return frag_q8(w[2 * ks], w[2 * ks + 1]);
+    if constexpr (BITS == 4) return frag_q4(u4_word(blk, ks));
+    else return frag_q8(u4_word(blk, 2 * ks), u4_word(blk, 2 * ks + 1));
+}
+
+// element g of a run of scale (or bias) values held in 16-byte registers v[0 ..]
+template <bool F32, int N>
+__device__ __forceinline__ float sb_reg(const uint4 (&v)[N], int base, int g) {
+    if constexpr (F32) return __uint_as_float(u4_word(v[base + g / 4], g % 4));
+    else {
+        const unsigned w = u4_word(v[base + g / 8], (g % 8) / 2);
+        return __uint_as_float((g & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -71,7 +95,16 @@ __global__ void quant_pack_q_kernel(const uint32_t* __restrict__ src, uint32_t* 
     unsigned* ow = reinterpret_cast<unsigned*>(&o);
     if (bits == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ow[i] = src[row * wpr + (kb * 4 + i) * 4 + fc];
+        for (int i = 0; i < 4; ++i) {
+            const unsigned w = src[row * wpr + (kb * 4 + i) * 4 + fc];          // checkpoint order: element j in bits [4j, 4j + 4)
+            unsigned r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                       // image order: pair (2k, 2k+1) in nibbles k, k + 4
+                r |= ((w >> (8 * k)) & 0xFu) << (4 * k);
+                r |= ((w >> (8 * k + 4)) & 0xFu) << (4 * k + 16);
+            }
+            ow[i] = r;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -193,6 +226,13 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
             for (int i = 0; i < XI; ++i) xr[i] = make_uint4(0, 0, 0, 0);
         }
     }
+    // norm weights: requested here, all at once (left inside the staging loop the compiler issues them one by one, each
+    // behind a full wait -- XI dependent round trips)
+    uint4 nwr[PRO == QPRO_RMSNORM ? XI : 1];
+    if constexpr (PRO == QPRO_RMSNORM) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
+    }
     // ---- 2. every packed weight block of this wave + the scales / biases of its groups --------------------
     uint4 wq[NT][KBW];
     float sc[NT][KBW][GPB], bi[NT][KBW][GPB];
@@ -208,9 +248,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
             for (int h = 0; h < GPB; ++h) {
                 const int g = (wave + WAVES * i) * GPB + h;
                 sc[t][i][h] = sb_at<SBF32>(a2.sb, ((tile * 2 + 0) * 16 + fr) * G + g);
-                bi[t][i][h] = sb_at<SBF32>(a2.sb, ((tile * 2 + 1) * 16 + fr) * G + g);
+                bi[t][i][h] = eff_bias<BITS>(sc[t][i][h], sb_at<SBF32>(a2.sb, ((tile * 2 + 1) * 16 + fr) * G + g));
             }
     }
+    // the requests above stay above: left to itself the scheduler sinks them below the RMSNorm reduction (five dependent
+    // cross-lane steps), i.e. the weights are asked for a microsecond late
+    __builtin_amdgcn_sched_barrier(0);
     // epilogue lane map: batch row = lane >> 2, four consecutive n at (lane & 3) * 4
     const int erow = lane >> 2, eq = lane & 3;
     uint2 rsd[NT][1];
@@ -233,15 +276,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
             }
-#pragma unroll
-            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            ss = lane_sum<TPR>(ss);
             inv = rsqrtf(ss / (float)K + a2.eps);
         }
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             uint4 o = xr[i];
             if constexpr (PRO == QPRO_RMSNORM) {
-                const uint4 nw = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
+                const uint4 nw = nwr[i];
                 const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
                 const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
                 bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
@@ -254,9 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
 #pragma unroll
             for (int j = 0; j < 8; ++j) p += bf16_to_f32(oe[j]);
             // chunk c = scol + TPR * i belongs to group c / 8: the 8 chunks of a group sit on 8 adjacent lanes
-            p += __shfl_xor(p, 1, 64);
-            p += __shfl_xor(p, 2, 64);
-            p += __shfl_xor(p, 4, 64);
+            p = lane_sum8(p);
             if ((scol & 7) == 0) s_xs[((scol + TPR * i) >> 3) * 16 + srow] = p;
         }
     }
@@ -339,8 +379,18 @@ static bool gemvq_k(const DecGemvQArgs& a2, hipStream_t s) {
 
 template <int BITS, bool SBF32>
 static bool gemvq_epi(DecEpi epi, bool norm, const DecGemvQArgs& a2, hipStream_t s) {
-    if (norm && epi == DEC_EPI_BF16) return gemvq_k<BITS, SBF32, 1, QPRO_RMSNORM, DEC_EPI_BF16>(a2, s);
-    if (norm && epi == DEC_EPI_SWIGLU) return gemvq_k<BITS, SBF32, 2, QPRO_RMSNORM, DEC_EPI_SWIGLU>(a2, s);
+    // RMSNorm staging (~500 vector instructions per thread) is replicated in every workgroup and sits on the critical path:
+    // at two workgroups per CU it takes twice as long, so the norm kernels take as many 16-row tiles per workgroup as
+    // leaves about one workgroup per CU at 32 batch rows (4096 / 32 x 2 = 256, 6144 / 64 x 2 = 192); the packed weights of
+    // the extra tiles are a few registers
+    if (norm && epi == DEC_EPI_BF16) {
+        if (a2.g.N % 32 == 0 && a2.g.N >= 4096) return gemvq_k<BITS, SBF32, 2, QPRO_RMSNORM, DEC_EPI_BF16>(a2, s);
+        return gemvq_k<BITS, SBF32, 1, QPRO_RMSNORM, DEC_EPI_BF16>(a2, s);
+    }
+    if (norm && epi == DEC_EPI_SWIGLU) {
+        if (a2.g.N % 64 == 0 && a2.g.N >= 6144) return gemvq_k<BITS, SBF32, 4, QPRO_RMSNORM, DEC_EPI_SWIGLU>(a2, s);
+        return gemvq_k<BITS, SBF32, 2, QPRO_RMSNORM, DEC_EPI_SWIGLU>(a2, s);
+    }
     if (!norm && epi == DEC_EPI_RESID) return gemvq_k<BITS, SBF32, 1, QPRO_COPY, DEC_EPI_RESID>(a2, s);
     return false;
 }
@@ -430,10 +480,13 @@ void decode_gemv_q_launch(DecEpi epi, const DecGemvArgs& a, const QuantImg& w, c
 
 // ------------------------------------------------------------------------------------------------
 // LM head on the quantised tied embedding, persistent form (cf. lm_head_kernel): batch rows normalised and staged once
-// per workgroup together with their group sums; every wave walks its own 16-row tiles over the full K with a two-deep
-// register pipeline (q blocks + the tile's scales / biases), no cross-wave reduction.  A lane owns weight row
-// n = tile * 16 + (lane & 15) and batch rows 4 (lane >> 4) .. + 3 of each batch tile; running argmax per batch row over
-// bf16-rounded logits, lowest index on ties.
+// per workgroup together with their group sums; every wave walks its own 16-row tiles over the full K, 512 columns
+// (8 groups) per step, no cross-wave reduction.  A lane owns weight row n = tile * 16 + (lane & 15) and batch rows
+// 4 (lane >> 4) .. + 3 of each batch tile; running argmax per batch row over bf16-rounded logits, lowest index on ties.
+// Weight pipeline: a ring of four 16-byte q blocks per lane, each slot refilled as soon as it has been consumed (4 KiB per
+// wave, 32 KiB per CU in flight: 1.9 TB/s, latency-bound; eight slots compile to 256 registers + scratch).  A two-deep pipeline of whole tiles (two register buffers) compiled to 256 registers
+// plus kilobytes of scratch per lane and ran 20x slower; hipcc also wants ~58 registers per batch tile for this loop
+// (166 / 224 at 16 / 32 rows), so the kernel runs one workgroup per CU at two waves per SIMD.
 // ------------------------------------------------------------------------------------------------
 constexpr int LMQ_WAVES = 8;
 
@@ -454,32 +507,41 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int BLK = BITS == 4 ? 128 : 64, GPB = BLK / 64, NBLK = K / BLK, G = K / 64;
     constexpr int KCH = K / 8, XSTRIDE = 2 * K + 16, TPR = 32, XI = KCH / TPR;
-    constexpr int SBV = G * (SBF32 ? 4 : 2) / 16;                 // 16-byte loads per lane for the scales (and for the biases)
-    static_assert(G * (SBF32 ? 4 : 2) % 16 == 0, "scale row must be a whole number of 16-byte loads");
+    constexpr int RING = 4;                                       // 16-byte q blocks in flight per lane
+    static_assert(NBLK % RING == 0, "K must be a multiple of 512");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
     char* s_x = dsm;                                                            // [NB*16][XSTRIDE]
     float* s_xs = reinterpret_cast<float*>(dsm + (size_t)NB * 16 * XSTRIDE);     // [G][NB*16]
     const int total_waves = gridDim.x * LMQ_WAVES, gw = blockIdx.x * LMQ_WAVES + wave;
     const int ntiles = a.N / 16;
     const int my_tiles = gw < ntiles ? (ntiles - gw + total_waves - 1) / total_waves : 0;
-    uint4 qa[NBLK], qb[NBLK], sa[2 * SBV], sbb[2 * SBV];
-    auto issue = [&](uint4 (&q)[NBLK], uint4 (&sv)[2 * SBV], int item) {
-        const long tile = gw + (long)item * total_waves;
-        const uint32_t* qp = a.qp + (tile * NBLK * 64 + lane) * 4;
+    const int nblocks = my_tiles * NBLK;
+    // ring slot r holds block (it * RING + r) of this wave's block sequence: the packed q words and the scale / bias of its
+    // GPB groups.  A slot is refilled right after it has been consumed, so RING blocks (4 KiB per wave) stay in flight
+    // without a second register buffer.
+    uint4 qr[RING];
+    float scr[RING][GPB], bir[RING][GPB];
+    auto load_blk = [&](uint4& q, float (&sc)[GPB], float (&bi)[GPB], int bi_seq) {
+        const long tile = gw + (long)(bi_seq / NBLK) * total_waves;
+        const int kb = bi_seq % NBLK;
+        q = *reinterpret_cast<const uint4*>(a.qp + ((tile * NBLK + kb) * 64 + lane) * 4);
 #pragma unroll
-        for (int i = 0; i < NBLK; ++i) q[i] = *reinterpret_cast<const uint4*>(qp + (long)i * 256);
-        const char* sp = reinterpret_cast<const char*>(a.sb) + ((tile * 2 * 16 + fr) * G) * (SBF32 ? 4 : 2);
-#pragma unroll
-        for (int i = 0; i < SBV; ++i) {
-            sv[i] = *reinterpret_cast<const uint4*>(sp + i * 16);
-            sv[SBV + i] = *reinterpret_cast<const uint4*>(sp + (size_t)16 * G * (SBF32 ? 4 : 2) + i * 16);
+        for (int h = 0; h < GPB; ++h) {
+            sc[h] = sb_at<SBF32>(a.sb, ((tile * 2 + 0) * 16 + fr) * G + kb * GPB + h);
+            bi[h] = eff_bias<BITS>(sc[h], sb_at<SBF32>(a.sb, ((tile * 2 + 1) * 16 + fr) * G + kb * GPB + h));
         }
     };
-    if (my_tiles > 0) issue(qa, sa, 0);
+    if (nblocks > 0) {
+#pragma unroll
+        for (int r = 0; r < RING; ++r) load_blk(qr[r], scr[r], bir[r], r);
+    }
     // ---- stage + RMSNorm the batch rows, 16 rows per pass; group sums of the staged values ------------------
     {
         const int srow = tid / TPR, scol = tid % TPR;
+        uint4 nwr[XI];
 #pragma unroll
+        for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
+#pragma unroll 1
         for (int nb = 0; nb < NB; ++nb) {
             const int r = nb * 16 + srow;
             const bool live = r < a.B;
@@ -494,13 +556,12 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
             }
-#pragma unroll
-            for (int ofs = 1; ofs < TPR; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            ss = lane_sum<TPR>(ss);
             const float inv = rsqrtf(ss / (float)K + a.eps);
             char* xrow = s_x + (size_t)r * XSTRIDE + scol * 16;
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
-                const uint4 nw = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
+                const uint4 nw = nwr[i];
                 const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
                 const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
                 uint4 o;
@@ -512,9 +573,7 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
                     p += bf16_to_f32(oe[j]);
                 }
                 *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
-                p += __shfl_xor(p, 1, 64);
-                p += __shfl_xor(p, 2, 64);
-                p += __shfl_xor(p, 4, 64);
+                p = lane_sum8(p);
                 if ((scol & 7) == 0) s_xs[((scol + TPR * i) >> 3) * (NB * 16) + r] = p;
             }
         }
@@ -522,58 +581,59 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
     __syncthreads();
     float best[NB][4];
     int bidx[NB][4];
+    f32x4 tot[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+        tot[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) { best[b][j] = -INFINITY; bidx[b][j] = 0x7fffffff; }
-    auto consume = [&](const uint4 (&q)[NBLK], const uint4 (&sv)[2 * SBV], int item) {
-        const int tile = gw + item * total_waves, n = tile * 16 + fr;
-        f32x4 tot[NB];
+    }
+#pragma unroll 1
+    for (int b0 = 0; b0 < nblocks; b0 += RING) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) tot[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NBLK; ++i)
+        for (int r = 0; r < RING; ++r) {
+            const int kb = (b0 + r) % NBLK;                       // block within the tile (RING divides NBLK: same tile for all r)
+            // fragments converted once, then used for every batch tile
+            mfma_bf16x8 wf[2 * GPB];
 #pragma unroll
             for (int h = 0; h < GPB; ++h) {
-                const int g = i * GPB + h;
-                float s, bv;
-                if constexpr (SBF32) {
-                    s = reinterpret_cast<const float*>(&sv[0])[g];
-                    bv = reinterpret_cast<const float*>(&sv[SBV])[g];
-                } else {
-                    s = bf16_to_f32(reinterpret_cast<const bf16_t*>(&sv[0])[g]);
-                    bv = bf16_to_f32(reinterpret_cast<const bf16_t*>(&sv[SBV])[g]);
-                }
-                const mfma_bf16x8 w0 = frag_of<BITS>(q[i], 2 * h + 0), w1 = frag_of<BITS>(q[i], 2 * h + 1);
+                wf[2 * h] = frag_of<BITS>(qr[r], 2 * h + 0);
+                wf[2 * h + 1] = frag_of<BITS>(qr[r], 2 * h + 1);
+            }
+            const float sg0 = scr[r][0], bg0 = bir[r][0], sg1 = scr[r][GPB - 1], bg1 = bir[r][GPB - 1];
+            if (b0 + RING < nblocks) load_blk(qr[r], scr[r], bir[r], b0 + RING + r);     // refill the slot at once
+            const char* xw = s_x + (size_t)fr * XSTRIDE + fc * 16 + (size_t)kb * GPB * 128;
+            const float* xsw = s_xs + (size_t)kb * GPB * (NB * 16) + fc * 4;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const char* xb = s_x + (size_t)(b * 16 + fr) * XSTRIDE + fc * 16;
-                    const uint4 x0 = *reinterpret_cast<const uint4*>(xb + (g * 2 + 0) * 64);
-                    const uint4 x1 = *reinterpret_cast<const uint4*>(xb + (g * 2 + 1) * 64);
-                    const f32x4 xs = *reinterpret_cast<const f32x4*>(s_xs + g * (NB * 16) + b * 16 + fc * 4);
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int h = 0; h < GPB; ++h) {
+                    const uint4 x0 = *reinterpret_cast<const uint4*>(xw + (size_t)b * 16 * XSTRIDE + (h * 2 + 0) * 64);
+                    const uint4 x1 = *reinterpret_cast<const uint4*>(xw + (size_t)b * 16 * XSTRIDE + (h * 2 + 1) * 64);
+                    const f32x4 xs = *reinterpret_cast<const f32x4*>(xsw + h * (NB * 16) + b * 16);
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x0), w0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x1), w1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x0), wf[2 * h], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x1), wf[2 * h + 1], acc, 0, 0, 0);
+                    const float sg = h == 0 ? sg0 : sg1, bg = h == 0 ? bg0 : bg1;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) tot[b][j] += s * acc[j] + bv * xs[j];
+                    for (int j = 0; j < 4; ++j) tot[b][j] += sg * acc[j] + bg * xs[j];
                 }
             }
+            // one block at a time: hoisting the LDS reads of later blocks costs more registers than the ring leaves
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((b0 + RING) % NBLK == 0) {                         // tile complete: tot[b][j] = logit[batch b*16 + fc*4 + j][n]
+            const int n = (gw + (b0 / NBLK) * total_waves) * 16 + fr;
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = b * 16 + fc * 4 + j;
-                const float v = bf16_round(tot[b][j]);
-                if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
-                if (v > best[b][j] || (v == best[b][j] && n < bidx[b][j])) { best[b][j] = v; bidx[b][j] = n; }
-            }
-    };
-    for (int item = 0; item < my_tiles; item += 2) {
-        if (item + 1 < my_tiles) issue(qb, sbb, item + 1);
-        consume(qa, sa, item);
-        if (item + 1 < my_tiles) {
-            if (item + 2 < my_tiles) issue(qa, sa, item + 2);
-            consume(qb, sbb, item + 1);
+                for (int j = 0; j < 4; ++j) {
+                    const int row = b * 16 + fc * 4 + j;
+                    const float v = bf16_round(tot[b][j]);
+                    if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
+                    if (v > best[b][j] || (v == best[b][j] && n < bidx[b][j])) { best[b][j] = v; bidx[b][j] = n; }
+                    tot[b][j] = 0.0f;
+                }
         }
     }
     // ---- argmax partial of the workgroup: over the 16 weight rows of a lane group, then over the waves ----------
