@@ -265,6 +265,56 @@ int qasr_align_batch(qasr_engine* e, const float* const* pcm, const size_t* n, s
 int qasr_align_long(qasr_engine* e, const float* pcm, size_t n, int sample_rate, const char* text,
                     const char* language, qasr_alignment* out);
 
+/* ---- Omnilingual ASR: wav2vec2 encoder + CTC head (BASELINE configs[3]) --------------------------------------------
+ * Replaces OmnilingualASRMLXModel (Sources/OmnilingualASR/MLX/OmnilingualMLXModel.swift:20-210) behind the same
+ * SpeechRecognitionModel surface (MLX/OmnilingualASRMLXModel+Protocols.swift:3-15): raw 16 kHz samples -> utterance
+ * layer-norm -> conv feature extractor -> positional encoder -> N pre-norm transformer layers -> CTC head -> per-frame argmax
+ * -> duplicate collapse -> SentencePiece text.  Language-agnostic (the `language` hint is ignored by the reference too);
+ * 40 s cap like the reference (:154-159): longer clips return QASR_ERR_CAPACITY.  Batched: clips of a call are independent. */
+typedef struct qasr_ctc_engine qasr_ctc_engine;
+typedef struct qasr_ctc_config {       /* OmnilingualMLXConfig (MLX/OmnilingualMLXConfig.swift:11-103) + engine capacity */
+    int32_t model_dim, layers, heads, ffn_dim;
+    int32_t feature_dim;               /* 512: conv feature extractor width; kernels [10,3,3,3,3,2,2], strides [5,2,2,2,2,2,2] */
+    int32_t pos_kernel, pos_groups;    /* 128, 16 */
+    int32_t vocab;                     /* 10288 */
+    int32_t group_size, bits;          /* MLX quantisation of the encoder / head linears: 64, 4 | 8 */
+    float ln_eps;                      /* 1e-5 */
+    int32_t device, max_batch;
+    int32_t max_audio_seconds;         /* <= 40 (the reference's cap) */
+} qasr_ctc_config;
+/* variant: "300M" | "1B" | "3B" | "7B", a model id such as "aufklarer/Omnilingual-ASR-CTC-1B-MLX-8bit" (detectVariant /
+ * detectBits, OmnilingualMLXModel.swift:121-133), or "tiny" (test geometry). */
+int qasr_ctc_default_config(const char* variant, qasr_ctc_config* out);
+/* model_dir: model.safetensors (+ tokenizer.model) as published (OmnilingualMLXWeightLoader.swift:12-37); NULL = empty
+ * engine filled through qasr_ctc_set_tensor (fairseq2 tensor names, PyTorch Conv1d layout, weight_g / weight_v). */
+int qasr_ctc_create(const char* model_dir, const qasr_ctc_config* cfg, qasr_ctc_engine** out);
+int qasr_ctc_set_tensor(qasr_ctc_engine* e, const char* name, const void* host_data, int dtype, const int64_t* shape, int ndim);
+int qasr_ctc_finalize(qasr_ctc_engine* e);
+/* SentencePiece vocabulary: piece texts + types (1 normal, 2 unknown, 3 control, 4 user, 5 unused, 6 byte) */
+int qasr_ctc_set_pieces(qasr_ctc_engine* e, const char* const* texts, const int32_t* types, size_t n);
+int qasr_ctc_is_loaded(const qasr_ctc_engine* e);
+int qasr_ctc_unload(qasr_ctc_engine* e);
+size_t qasr_ctc_memory_footprint(const qasr_ctc_engine* e);
+void qasr_ctc_destroy(qasr_ctc_engine* e);
+const char* qasr_ctc_last_error(const qasr_ctc_engine* e);
+/* encoder frames for n samples (Wav2Vec2FeatureExtractor.outputLength, Wav2Vec2Frontend.swift:47-54): 160000 -> 499 */
+int qasr_ctc_num_frames(size_t n_samples);
+/* ids: [B][stride] collapsed token ids of every clip (argmax per frame, consecutive duplicates removed, blank kept:
+ * OmnilingualMLXModel.swift:183-188), lens[b] = count; stride >= qasr_ctc_num_frames(longest clip). */
+int qasr_ctc_transcribe_batch(qasr_ctc_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
+                              int32_t* ids, size_t stride, int32_t* lens);
+/* transcribe(audio:sampleRate:language:) -> text owned by the engine until its next call; "" for an empty clip */
+int qasr_ctc_transcribe(qasr_ctc_engine* e, const float* pcm, size_t n, int sample_rate, const char** text);
+/* stage entry point (oracle diffing): logits [frames][vocab] f32 of one clip */
+int qasr_ctc_logits(qasr_ctc_engine* e, const float* pcm, size_t n, float* logits);
+int qasr_ctc_detokenize(qasr_ctc_engine* e, const int32_t* ids, int32_t n, char* buf, size_t cap);
+/* device time of the last call, ms: [0] feature extractor + positional encoder [1] transformer [2] head + argmax [3] total */
+int qasr_ctc_timings(qasr_ctc_engine* e, float ms[4]);
+/* pure CPU: CTCGreedyDecoder.decode (CTCGreedyDecoder.swift:28-55) -> count; OmnilingualASRModel.layerNormalize
+ * (OmnilingualASR.swift:305-325) */
+int qasr_ctc_greedy(const float* logits, int32_t T, int32_t V, int32_t valid_frames, int32_t* out);
+int qasr_layer_normalize(const float* x, size_t n, float eps, float* out);
+
 #ifdef __cplusplus
 }
 #endif

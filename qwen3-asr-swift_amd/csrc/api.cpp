@@ -1,5 +1,6 @@
 // api.cpp -- extern "C" boundary (include/qasr.h).  Exceptions never cross it.
 #include "engine.h"
+#include "ctc_engine.h"
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -413,6 +414,158 @@ int qasr_prefill_logits(qasr_engine* e, const float* audio_embeds, int n_audio, 
 int qasr_decode_forced(qasr_engine* e, const int32_t* tokens, int n, float* logits) {
     if (!e || !tokens || !logits || n < 0) return QASR_ERR_INVALID;
     QASR_GUARD(e, e->impl->decode_forced_host(tokens, n, logits));
+}
+
+// ---- Omnilingual ASR (wav2vec2 + CTC) -------------------------------------------------------------------
+}  // extern "C"
+
+struct qasr_ctc_engine {
+    std::unique_ptr<qasr::CtcEngine> impl;
+};
+static int cfail(qasr_ctc_engine* e, int code, const std::string& msg) {
+    if (e && e->impl) e->impl->last_error = msg; else g_create_error = msg;
+    return code;
+}
+#define QASR_CGUARD(e, body)                                                          \
+    try { body; return QASR_OK; }                                                     \
+    catch (const qasr::HipError& ex) { return cfail(e, QASR_ERR_HIP, ex.what()); }    \
+    catch (const qasr::NotLoaded& ex) { return cfail(e, QASR_ERR_NOT_LOADED, ex.what()); } \
+    catch (const std::invalid_argument& ex) { return cfail(e, QASR_ERR_INVALID, ex.what()); } \
+    catch (const std::length_error& ex) { return cfail(e, QASR_ERR_CAPACITY, ex.what()); }    \
+    catch (const std::exception& ex) { return cfail(e, QASR_ERR_INVALID, ex.what()); }
+
+extern "C" {
+
+int qasr_ctc_default_config(const char* variant, qasr_ctc_config* c) {
+    if (!c) return QASR_ERR_INVALID;
+    const std::string v = variant ? variant : "300M";
+    std::memset(c, 0, sizeof(*c));
+    c->feature_dim = 512; c->pos_kernel = 128; c->pos_groups = 16; c->vocab = 10288; c->group_size = 64; c->bits = 4;
+    c->ln_eps = 1e-5f; c->device = 0; c->max_batch = 32; c->max_audio_seconds = 40;
+    if (v == "tiny") {               // oracle/omnilingual.py OMNI_TINY
+        c->model_dim = 64; c->layers = 2; c->heads = 2; c->ffn_dim = 128; c->feature_dim = 32; c->pos_kernel = 16; c->pos_groups = 4;
+        c->vocab = 40; c->bits = 16; c->max_batch = 8; c->max_audio_seconds = 10;
+        return QASR_OK;
+    }
+    // OmnilingualMLXConfig.variant (:88-103); detectVariant looks for "CTC-<size>-" in a model id (OmnilingualMLXModel.swift:121-126)
+    struct V { const char* name; int d, l, h, f; };
+    static const V table[] = {{"300M", 1024, 24, 16, 4096}, {"1B", 1280, 48, 20, 5120}, {"3B", 2048, 60, 32, 8192}, {"7B", 2048, 128, 32, 8192}};
+    const V* pick = nullptr;
+    for (const V& t : table)
+        if (v == t.name || contains(v, (std::string("CTC-") + t.name + "-").c_str())) pick = &t;
+    if (!pick) return QASR_ERR_INVALID;
+    c->model_dim = pick->d; c->layers = pick->l; c->heads = pick->h; c->ffn_dim = pick->f;
+    if (contains(v, "8bit")) c->bits = 8;      // detectBits (:128-132)
+    return QASR_OK;
+}
+
+int qasr_ctc_create(const char* model_dir, const qasr_ctc_config* cfg, qasr_ctc_engine** out) {
+    if (!cfg || !out) return QASR_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->max_audio_seconds > 40 || cfg->max_audio_seconds <= 0 || cfg->max_batch <= 0) {
+        g_create_error = "omnilingual: max_audio_seconds must be in 1..40 (the reference's cap), max_batch positive";
+        return QASR_ERR_INVALID;
+    }
+    qasr_ctc_engine* e = new qasr_ctc_engine();
+    try {
+        e->impl.reset(new qasr::CtcEngine(*cfg));
+        if (model_dir) { e->impl->load_directory(model_dir); e->impl->finalize(); }
+    } catch (const qasr::HipError& ex) { g_create_error = ex.what(); delete e; return QASR_ERR_HIP; }
+    catch (const std::exception& ex) { g_create_error = ex.what(); delete e; return model_dir ? QASR_ERR_IO : QASR_ERR_INVALID; }
+    *out = e;
+    return QASR_OK;
+}
+int qasr_ctc_set_tensor(qasr_ctc_engine* e, const char* name, const void* host, int dtype, const int64_t* shape, int ndim) {
+    if (!e || !name || !host || !shape || ndim <= 0) return QASR_ERR_INVALID;
+    QASR_CGUARD(e, e->impl->set_tensor(name, host, dtype, shape, ndim));
+}
+int qasr_ctc_finalize(qasr_ctc_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_CGUARD(e, e->impl->finalize()); }
+int qasr_ctc_set_pieces(qasr_ctc_engine* e, const char* const* texts, const int32_t* types, size_t n) {
+    if (!e || (!texts && n)) return QASR_ERR_INVALID;
+    QASR_CGUARD(e, e->impl->set_pieces(texts, types, n));
+}
+int qasr_ctc_is_loaded(const qasr_ctc_engine* e) { return e && e->impl->loaded(); }
+int qasr_ctc_unload(qasr_ctc_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_CGUARD(e, e->impl->unload()); }
+size_t qasr_ctc_memory_footprint(const qasr_ctc_engine* e) { return e ? e->impl->memory_footprint() : 0; }
+void qasr_ctc_destroy(qasr_ctc_engine* e) { delete e; }
+const char* qasr_ctc_last_error(const qasr_ctc_engine* e) { return e ? e->impl->last_error.c_str() : g_create_error.c_str(); }
+int qasr_ctc_num_frames(size_t n) { return qasr::CtcEngine::num_frames((long)n); }
+
+static int ctc_run(qasr_ctc_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
+                   std::vector<std::vector<int32_t>>& collapsed, float* logits) {
+    if (sample_rate != 16000) return cfail(e, QASR_ERR_INVALID, "only 16 kHz input is supported (resampler is out of scope)");
+    if (!e->impl->loaded()) return cfail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
+    for (size_t b = 0; b < B; ++b) {
+        if (!pcm[b] || n[b] == 0) return cfail(e, QASR_ERR_EMPTY_AUDIO, "empty clip in batch");
+        // OmnilingualMLXModel.swift:154-159: the 40 s cap is an error, not a truncation
+        if ((double)n[b] / 16000.0 > 40.0) return cfail(e, QASR_ERR_CAPACITY, "input exceeds the Omnilingual cap of 40 s");
+    }
+    QASR_CGUARD(e, {
+        std::vector<std::vector<int32_t>> frames;
+        e->impl->forward(pcm, n, B, frames, logits);
+        collapsed.assign(B, {});
+        for (size_t b = 0; b < B; ++b) {                    // collapseConsecutiveDuplicates (:195-209)
+            int prev = -1;
+            for (int32_t id : frames[b]) if (id != prev) { collapsed[b].push_back(id); prev = id; }
+        }
+    });
+}
+
+int qasr_ctc_transcribe_batch(qasr_ctc_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
+                              int32_t* ids, size_t stride, int32_t* lens) {
+    if (!e || !pcm || !n || !ids || !lens || B == 0) return QASR_ERR_INVALID;
+    std::vector<std::vector<int32_t>> col;
+    if (int rc = ctc_run(e, pcm, n, B, sample_rate, col, nullptr)) return rc;
+    for (size_t b = 0; b < B; ++b) {
+        if (col[b].size() > stride) return cfail(e, QASR_ERR_CAPACITY, "ctc_transcribe_batch: id buffer stride too small");
+        std::memcpy(ids + b * stride, col[b].data(), col[b].size() * sizeof(int32_t));
+        lens[b] = (int32_t)col[b].size();
+    }
+    return QASR_OK;
+}
+
+int qasr_ctc_transcribe(qasr_ctc_engine* e, const float* pcm, size_t n, int sample_rate, const char** text) {
+    if (!e || !text) return QASR_ERR_INVALID;
+    if (n == 0) { e->impl->result_text.clear(); *text = e->impl->result_text.c_str(); return QASR_OK; }     // :160-162
+    if (!pcm) return QASR_ERR_INVALID;
+    std::vector<std::vector<int32_t>> col;
+    if (int rc = ctc_run(e, &pcm, &n, 1, sample_rate, col, nullptr)) return rc;
+    try { e->impl->result_text = e->impl->detokenize(col[0].data(), (int)col[0].size()); }
+    catch (const std::exception& ex) { return cfail(e, QASR_ERR_INVALID, ex.what()); }
+    *text = e->impl->result_text.c_str();
+    return QASR_OK;
+}
+
+int qasr_ctc_logits(qasr_ctc_engine* e, const float* pcm, size_t n, float* logits) {
+    if (!e || !pcm || !logits) return QASR_ERR_INVALID;
+    std::vector<std::vector<int32_t>> col;
+    return ctc_run(e, &pcm, &n, 1, 16000, col, logits);
+}
+
+int qasr_ctc_detokenize(qasr_ctc_engine* e, const int32_t* ids, int32_t n, char* buf, size_t cap) {
+    if (!e || (!ids && n) || !buf || cap == 0 || n < 0) return -1;
+    try {
+        std::string t = e->impl->detokenize(ids, n);
+        if (t.size() + 1 > cap) { cfail(e, QASR_ERR_CAPACITY, "detokenize: buffer too small"); return -1; }
+        std::memcpy(buf, t.c_str(), t.size() + 1);
+        return (int)t.size();
+    } catch (const std::exception& ex) { cfail(e, QASR_ERR_INVALID, ex.what()); return -1; }
+}
+
+int qasr_ctc_timings(qasr_ctc_engine* e, float ms[4]) {
+    if (!e || !ms) return QASR_ERR_INVALID;
+    QASR_CGUARD(e, e->impl->timings(ms));
+}
+
+int qasr_ctc_greedy(const float* logits, int32_t T, int32_t V, int32_t valid_frames, int32_t* out) {
+    if (T < 0 || V <= 0 || (T > 0 && (!logits || !out))) return -QASR_ERR_INVALID;
+    return qasr::ctc_greedy_decode(logits, T, V, valid_frames, out);
+}
+
+int qasr_layer_normalize(const float* x, size_t n, float eps, float* out) {
+    if ((!x || !out) && n) return QASR_ERR_INVALID;
+    qasr::layer_normalize_host(x, n, eps, out);
+    return QASR_OK;
 }
 
 }  // extern "C"

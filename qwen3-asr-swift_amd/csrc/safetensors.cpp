@@ -7,6 +7,7 @@
 //                  f32 (exact) so no checkpoint value is rounded.
 #include "engine.h"
 #include "json.h"
+#include "safetensors.h"
 #include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -17,12 +18,11 @@
 
 namespace qasr {
 
-namespace {
-struct Mapped {
+struct SafeTensorsDir::Mapping {
     void* p = MAP_FAILED;
     size_t n = 0;
     int fd = -1;
-    explicit Mapped(const std::string& path) {
+    explicit Mapping(const std::string& path) {
         fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) throw std::runtime_error("cannot open " + path);
         struct stat st;
@@ -31,19 +31,13 @@ struct Mapped {
         p = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
         if (p == MAP_FAILED) { ::close(fd); throw std::runtime_error("cannot mmap " + path); }
     }
-    ~Mapped() {
+    ~Mapping() {
         if (p != MAP_FAILED) munmap(p, n);
         if (fd >= 0) ::close(fd);
     }
 };
 
-struct Entry {
-    std::string dtype;
-    std::vector<int64_t> shape;
-    const uint8_t* data;
-    size_t bytes;
-};
-
+namespace {
 float half_to_float(uint16_t h) {
     uint32_t sign = (h & 0x8000u) << 16, exp = (h >> 10) & 0x1F, man = h & 0x3FF, out;
     if (exp == 0) {
@@ -59,8 +53,9 @@ float half_to_float(uint16_t h) {
     std::memcpy(&f, &out, 4);
     return f;
 }
+}  // namespace
 
-float elem_f32(const Entry& e, size_t i) {
+float safe_elem_f32(const SafeEntry& e, size_t i) {
     if (e.dtype == "F32") { float f; std::memcpy(&f, e.data + 4 * i, 4); return f; }
     uint16_t h;
     std::memcpy(&h, e.data + 2 * i, 2);
@@ -68,9 +63,10 @@ float elem_f32(const Entry& e, size_t i) {
     if (e.dtype == "F16") return half_to_float(h);
     throw std::runtime_error("unsupported float dtype " + e.dtype);
 }
-}  // namespace
 
-void Engine::load_directory(const std::string& dir) {
+SafeTensorsDir::~SafeTensorsDir() = default;
+
+SafeTensorsDir::SafeTensorsDir(const std::string& dir) {
     std::vector<std::string> files;
     if (DIR* d = opendir(dir.c_str())) {
         while (dirent* de = readdir(d)) {
@@ -81,12 +77,10 @@ void Engine::load_directory(const std::string& dir) {
     } else throw std::runtime_error("cannot open model directory " + dir);
     if (files.empty()) throw std::runtime_error("no .safetensors files in " + dir);
     std::sort(files.begin(), files.end());
-    std::vector<std::unique_ptr<Mapped>> maps;
-    std::map<std::string, Entry> entries;
     for (auto& f : files) {
-        maps.push_back(std::make_unique<Mapped>(f));
-        const uint8_t* base = (const uint8_t*)maps.back()->p;
-        const size_t n = maps.back()->n;
+        maps_.push_back(std::make_unique<Mapping>(f));
+        const uint8_t* base = (const uint8_t*)maps_.back()->p;
+        const size_t n = maps_.back()->n;
         if (n < 8) throw std::runtime_error("truncated safetensors file " + f);
         uint64_t hlen;
         std::memcpy(&hlen, base, 8);
@@ -98,7 +92,7 @@ void Engine::load_directory(const std::string& dir) {
             if (kv.first == "__metadata__") continue;
             const Json *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
             if (!dt || !sh || !off || off->arr.size() != 2) throw std::runtime_error("bad tensor entry " + kv.first);
-            Entry e;
+            SafeEntry e;
             e.dtype = dt->str;
             for (auto& d : sh->arr) {
                 if (d.type != Json::Num || d.num < 0 || d.num > 9.0e15 || d.num != (double)(int64_t)d.num)
@@ -119,6 +113,13 @@ void Engine::load_directory(const std::string& dir) {
             entries[kv.first] = e;
         }
     }
+}
+
+void Engine::load_directory(const std::string& dir) {
+    SafeTensorsDir st(dir);
+    std::map<std::string, SafeEntry>& entries = st.entries;
+    typedef SafeEntry Entry;
+    auto elem_f32 = [](const Entry& e, size_t i) { return safe_elem_f32(e, i); };
     std::vector<bf16_t> tmp;
     auto upload_float = [&](const std::string& name, const Entry& e) {
         size_t numel = 1;

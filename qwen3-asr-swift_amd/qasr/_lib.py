@@ -21,6 +21,13 @@ class QasrConfig(C.Structure):
                [("timestamp_segment_time", C.c_float)]
 
 
+class QasrCtcConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("model_dim", "layers", "heads", "ffn_dim", "feature_dim", "pos_kernel", "pos_groups",
+                                         "vocab", "group_size", "bits")] + \
+               [("ln_eps", C.c_float)] + \
+               [(n, C.c_int32) for n in ("device", "max_batch", "max_audio_seconds")]
+
+
 class QasrOptions(C.Structure):
     _fields_ = [("max_tokens", C.c_int32), ("ignore_eos", C.c_int32),
                 ("context_ids", C.POINTER(C.c_int32)), ("n_context", C.c_int32),
@@ -109,6 +116,24 @@ SIGNATURES = {
     "qasr_align_words": (C.c_int, [_E, _F, C.c_size_t, C.c_int, _P(C.c_char_p), _P(C.c_char_p), C.c_size_t, _P(QasrAlignment)]),
     "qasr_align_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(C.c_char_p), C.c_char_p, _P(QasrAlignment)]),
     "qasr_align_long": (C.c_int, [_E, _F, C.c_size_t, C.c_int, C.c_char_p, C.c_char_p, _P(QasrAlignment)]),
+    "qasr_ctc_default_config": (C.c_int, [C.c_char_p, _P(QasrCtcConfig)]),
+    "qasr_ctc_create": (C.c_int, [C.c_char_p, _P(QasrCtcConfig), _P(_E)]),
+    "qasr_ctc_set_tensor": (C.c_int, [_E, C.c_char_p, C.c_void_p, C.c_int, _P(C.c_int64), C.c_int]),
+    "qasr_ctc_finalize": (C.c_int, [_E]),
+    "qasr_ctc_set_pieces": (C.c_int, [_E, _P(C.c_char_p), _I, C.c_size_t]),
+    "qasr_ctc_is_loaded": (C.c_int, [_E]),
+    "qasr_ctc_unload": (C.c_int, [_E]),
+    "qasr_ctc_memory_footprint": (C.c_size_t, [_E]),
+    "qasr_ctc_destroy": (None, [_E]),
+    "qasr_ctc_last_error": (C.c_char_p, [_E]),
+    "qasr_ctc_num_frames": (C.c_int, [C.c_size_t]),
+    "qasr_ctc_transcribe_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _I, C.c_size_t, _I]),
+    "qasr_ctc_transcribe": (C.c_int, [_E, _F, C.c_size_t, C.c_int, _P(C.c_char_p)]),
+    "qasr_ctc_logits": (C.c_int, [_E, _F, C.c_size_t, _F]),
+    "qasr_ctc_detokenize": (C.c_int, [_E, _I, C.c_int32, C.c_char_p, C.c_size_t]),
+    "qasr_ctc_timings": (C.c_int, [_E, _F]),
+    "qasr_ctc_greedy": (C.c_int, [_F, C.c_int32, C.c_int32, C.c_int32, _I]),
+    "qasr_layer_normalize": (C.c_int, [_F, C.c_size_t, C.c_float, _F]),
 }
 
 _lib = None

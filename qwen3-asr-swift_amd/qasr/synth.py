@@ -139,3 +139,57 @@ def quantize_state_dict(sd, bits, group=QUANT_GROUP):
         else:
             out[k] = v
     return out
+
+
+def synth_omnilingual_state_dict(cfg, seed=0, bits=0, dtype=torch.float32):
+    """Seeded random weights of an Omnilingual (wav2vec2-CTC) model under the reference's fairseq2 tensor names
+    (MLX/OmnilingualMLXWeightLoader.swift:40-135): PyTorch Conv1d layout [out, in, k], weight_g / weight_v for the
+    positional conv, every encoder / head Linear with a bias.  cfg: object with model_dim, layers, heads, ffn_dim,
+    feature_dim, pos_kernel, pos_groups, vocab.  bits 4 / 8: the encoder and head linears as MLX triplets (f32 scales, as
+    the reference's loader widens them), else float weights."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    kernels = (10, 3, 3, 3, 3, 2, 2)
+
+    def rnd(*shape, std):
+        return (torch.randn(*shape, generator=g) * std).to(dtype)
+
+    C, D, F = cfg.feature_dim, cfg.model_dim, cfg.ffn_dim
+    for i, k in enumerate(kernels):
+        p = f"encoder_frontend.feature_extractor.layers.{i}"
+        cin = 1 if i == 0 else C
+        sd[p + ".conv.weight"] = rnd(C, cin, k, std=1.0 / math.sqrt(cin * k))
+        sd[p + ".conv.bias"] = rnd(C, std=0.05)
+        sd[p + ".layer_norm.weight"] = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dtype)
+        sd[p + ".layer_norm.bias"] = rnd(C, std=0.05)
+    sd["encoder_frontend.post_extract_layer_norm.weight"] = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dtype)
+    sd["encoder_frontend.post_extract_layer_norm.bias"] = rnd(C, std=0.05)
+    sd["encoder_frontend.model_dim_proj.weight"] = rnd(D, C, std=1.0 / math.sqrt(C))
+    sd["encoder_frontend.model_dim_proj.bias"] = rnd(D, std=0.05)
+    cpg = D // cfg.pos_groups
+    sd["encoder_frontend.pos_encoder.conv.weight_v"] = rnd(D, cpg, cfg.pos_kernel, std=1.0)
+    sd["encoder_frontend.pos_encoder.conv.weight_g"] = (0.5 + 0.1 * torch.randn(1, 1, cfg.pos_kernel, generator=g)).abs().to(dtype)
+    sd["encoder_frontend.pos_encoder.conv.bias"] = rnd(D, std=0.05)
+
+    def lin(stem, n, k):
+        w = rnd(n, k, std=1.0 / math.sqrt(k))
+        if bits in (4, 8):
+            wq, s, b = quantize_linear(w.to(torch.bfloat16), bits)
+            sd[stem + ".weight"], sd[stem + ".scales"], sd[stem + ".biases"] = wq, s.to(torch.float32), b.to(torch.float32)
+        else:
+            sd[stem + ".weight"] = w
+        sd[stem + ".bias"] = rnd(n, std=0.05)
+
+    for l in range(cfg.layers):
+        p = f"encoder.layers.{l}"
+        for nme in ("q_proj", "k_proj", "v_proj", "output_proj"):
+            lin(f"{p}.self_attn.{nme}", D, D)
+        lin(f"{p}.ffn.inner_proj", F, D)
+        lin(f"{p}.ffn.output_proj", D, F)
+        for nme in ("self_attn_layer_norm", "ffn_layer_norm"):
+            sd[f"{p}.{nme}.weight"] = (1.0 + 0.1 * torch.randn(D, generator=g)).to(dtype)
+            sd[f"{p}.{nme}.bias"] = rnd(D, std=0.05)
+    sd["encoder.layer_norm.weight"] = (1.0 + 0.1 * torch.randn(D, generator=g)).to(dtype)
+    sd["encoder.layer_norm.bias"] = rnd(D, std=0.05)
+    lin("final_proj", cfg.vocab, D)
+    return sd

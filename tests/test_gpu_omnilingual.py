@@ -1,0 +1,185 @@
+"""Omnilingual ASR (wav2vec2 encoder + CTC head, BASELINE configs[3]) on the device vs the CPU oracle, via the C ABI.
+
+Bars (stated): the reference computes everything in f32 (its loader widens every tensor); the device rounds the inputs of
+every contraction to bf16 (MFMA operands) and keeps LayerNorm / residual / softmax statistics / bias in f32 -- oracle policy
+DEVICE.  Logits: relative L2 < 1e-2 vs DEVICE and < 2e-2 vs REFERENCE (the cost of the bf16 operands, same bars as the
+Qwen3 audio encoder).  Tokens: the device's per-frame argmax must be the oracle's argmax wherever the oracle's top-2 margin
+exceeds the logit tolerance (max |d| of that clip), and the collapsed id sequences obey the reference's integer semantics
+exactly (duplicate collapse, batch invariance, 40 s cap, empty input)."""
+import dataclasses
+import numpy as np
+import pytest
+import torch
+from conftest import GOLDEN
+from oracle import omnilingual as O, precision as P
+from qasr import synth
+from qasr.omnilingual import OmnilingualASRMLXModel
+from qasr.model import QasrError
+import os
+
+pytestmark = pytest.mark.gpu
+
+
+def _wave(k, seconds):
+    return synth.synth_waveform(k, seconds)
+
+
+def _check_logits(m, sd, cfg, pcm, what):
+    got = m.logits(pcm)
+    W = O.OmniWeights(sd)
+    with torch.no_grad():
+        dev = O.forward(pcm, W, cfg, P.DEVICE).numpy()
+        ref = O.forward(pcm, W, cfg, P.REFERENCE).numpy()
+    assert got.shape == dev.shape == (O.output_length(len(pcm)), cfg.vocab)
+    rd = np.linalg.norm(got - dev) / np.linalg.norm(dev)
+    rr = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    tol = float(np.abs(got - dev).max())
+    print(f"{what}: rel-L2 vs DEVICE {rd:.2e} vs REFERENCE {rr:.2e}, max|d| {tol:.3e}")
+    assert rd < 1e-2 and rr < 2e-2
+    top2 = np.sort(dev, axis=1)[:, -2:]
+    sure = (top2[:, 1] - top2[:, 0]) > 2 * tol
+    assert (got.argmax(1)[sure] == dev.argmax(1)[sure]).all() and sure.mean() > 0.5
+    return got
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    sd = synth.synth_omnilingual_state_dict(O.OMNI_TINY, seed=1)
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="tiny", max_batch=6, max_audio_seconds=12)
+    yield m, sd
+    m.close()
+
+
+@pytest.mark.parametrize("n", [400, 401, 721, 3000, 16000, 52345, 160000])
+def test_tiny_logits_vs_oracle(tiny, n):
+    """1 frame (400 samples = the receptive field), odd lengths, 10 s; every conv layer's floor((L - k) / s) + 1 edge."""
+    m, sd = tiny
+    pcm = _wave(n % 7, 11.0)[:n]
+    _check_logits(m, sd, O.OMNI_TINY, pcm, f"tiny n={n}")
+
+
+def test_hf_golden_weights_on_device(tiny):
+    """The weights of the transformers-generated golden through the engine: device logits vs the golden's own logits."""
+    G = np.load(os.path.join(GOLDEN, "hf_tiny_w2v.npz"))
+    sd = {k[3:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("sd/")}
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="tiny", max_batch=2, max_audio_seconds=2)
+    try:
+        for name in "abc":
+            got = m.logits(G["wave/" + name])
+            ref = G["logits/" + name]
+            rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            print(name, "rel-L2 vs transformers", rel)
+            assert rel < 2e-2
+    finally:
+        m.close()
+
+
+def test_batch_semantics_and_text(tiny):
+    m, sd = tiny
+    clips = [_wave(0, 2.5), _wave(1, 0.9), _wave(2, 0.03), _wave(3, 7.3)]
+    out = m.transcribe_batch(clips)
+    assert m.transcribe_batch(clips) == out                                   # deterministic
+    for c, ids in zip(clips, out):
+        assert m.transcribe_batch([c])[0] == ids                              # batch invariance, bit for bit
+        assert all(a != b for a, b in zip(ids, ids[1:]))                       # consecutive duplicates collapsed
+        assert len(ids) <= O.output_length(len(c))
+    assert m.transcribe_batch([clips[3], clips[0]]) == [out[3], out[0]]
+    # teacher check against the oracle: collapsed ids equal wherever every frame's argmax is unambiguous
+    with torch.no_grad():
+        for c, ids in zip(clips[:2], out[:2]):
+            lg = O.forward(c, sd, O.OMNI_TINY, P.DEVICE).numpy()
+            got = m.logits(c)
+            tol = float(np.abs(got - lg).max())
+            top2 = np.sort(lg, axis=1)[:, -2:]
+            if ((top2[:, 1] - top2[:, 0]) > 2 * tol).all():
+                assert ids == O.collapse(lg.argmax(1).tolist())
+    # vocabulary: OmnilingualVocabulary.decode rules through the C ABI
+    pieces = [("<s>", 3), ("<pad>", 3), ("</s>", 3), ("<unk>", 2)] + [("▁w%d" % i if i % 3 == 0 else "x%d" % i, 1) for i in range(4, 40)]
+    pieces[7] = ("<0x41>", 6)
+    m.set_pieces(pieces)
+    for ids in out:
+        assert m.detokenize(ids) == O.vocab_decode(ids, pieces)
+    assert m.transcribe_audio(clips[0]) == O.vocab_decode(out[0], pieces)
+    assert m.detokenize([0, 1, 2, 3, 7, 99]) == ""
+
+
+def test_reference_error_behaviour(tiny):
+    """40 s cap is an error, not a truncation (OmnilingualMLXModel.swift:154-159); empty input -> "" (:160-162); the
+    protocol surface never raises (OmnilingualASRMLXModel+Protocols.swift:8-14); unloaded model refuses."""
+    m, sd = tiny
+    long_clip = np.zeros(16000 * 41, np.float32)
+    with pytest.raises(QasrError, match="qasr error 5"):
+        m.transcribe_audio(long_clip)
+    assert m.transcribe(long_clip) == ""
+    assert m.transcribe_audio(np.zeros(0, np.float32)) == ""
+    with pytest.raises(QasrError, match="qasr error 5"):
+        m.transcribe_audio(np.zeros(16000 * 13, np.float32))                  # above this engine's own capacity (12 s)
+    assert m.transcribe(np.ones(3000, np.float32), sample_rate=8000) == ""
+    m2 = OmnilingualASRMLXModel.from_state_dict(sd, variant="tiny", max_batch=1, max_audio_seconds=2)
+    try:
+        assert m2.is_loaded and m2.memory_footprint > 0
+        m2.unload()
+        assert not m2.is_loaded and m2.memory_footprint == 0
+        assert m2.transcribe(np.ones(3000, np.float32)) == ""
+        with pytest.raises(QasrError, match="qasr error 3"):
+            m2.transcribe_audio(np.ones(3000, np.float32))
+    finally:
+        m2.close()
+
+
+@pytest.mark.parametrize("bits", [0, 4, 8], ids=["float", "mlx-4bit", "mlx-8bit"])
+def test_300m_width_two_layers(bits):
+    """Omnilingual-300M widths (D 1024, 16 heads x 64, FFN 4096, 512-channel extractor, k = 128 / 16-group positional conv,
+    vocab 10288) with 2 transformer layers so the CPU oracle stays affordable; float and MLX-quantised linears."""
+    cfg = dataclasses.replace(O.VARIANTS["300M"], layers=2)
+    sd = synth.synth_omnilingual_state_dict(cfg, seed=2, bits=bits)
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="300M", layers=2, bits=bits if bits else 4, max_batch=4, max_audio_seconds=6)
+    try:
+        pcm = _wave(1, 5.0)
+        _check_logits(m, sd, cfg, pcm, f"300M-width bits={bits}")
+        clips = [_wave(k, 1.0 + 0.7 * k) for k in range(4)]
+        out = m.transcribe_batch(clips)
+        assert m.transcribe_batch([clips[2]])[0] == out[2]
+    finally:
+        m.close()
+
+
+def test_safetensors_directory_with_sentencepiece(tmp_path):
+    """model.safetensors (f16 floats + uint32 triplets, as published) + tokenizer.model (SentencePiece protobuf) through
+    qasr_ctc_create == the same tensors through qasr_ctc_set_tensor."""
+    from safetensors.torch import save_file
+    import json
+    sd = synth.synth_omnilingual_state_dict(O.OMNI_TINY, seed=4, bits=8)
+    disk = {k: (v if v.dtype == torch.int32 else v.to(torch.float16)) for k, v in sd.items()}
+    path = tmp_path / "model.safetensors"
+    save_file({k: v.contiguous() for k, v in disk.items()}, str(path))
+    raw = path.read_bytes()
+    hlen = int.from_bytes(raw[:8], "little")
+    header = json.loads(raw[8:8 + hlen])
+    for k, v in header.items():
+        if k != "__metadata__" and v["dtype"] == "I32":
+            v["dtype"] = "U32"
+    hb = json.dumps(header, separators=(",", ":")).encode()
+    hb += b" " * (hlen - len(hb))
+    path.write_bytes(raw[:8] + hb + raw[8 + hlen:])
+    # minimal SentencePiece ModelProto: repeated field 1 { 1: piece, 2: score (fixed32), 3: type }
+    pieces = [("<s>", 3), ("<pad>", 3), ("</s>", 3), ("<unk>", 2)] + [("▁t%d" % i, 1) for i in range(4, 40)]
+    blob = b""
+    for text, typ in pieces:
+        t = text.encode("utf-8")
+        inner = b"\x0a" + bytes([len(t)]) + t + b"\x15" + np.float32(-1.5).tobytes() + (b"" if typ == 1 else b"\x18" + bytes([typ]))
+        blob += b"\x0a" + bytes([len(inner)]) + inner
+    blob += b"\x12\x02\x08\x01"                                   # an unrelated field (trainer_spec) the reader must skip
+    (tmp_path / "tokenizer.model").write_bytes(blob)
+    expect = {k: (v if v.dtype == torch.int32 else v.to(torch.float16).to(torch.float32)) for k, v in sd.items()}
+    m = OmnilingualASRMLXModel(variant="tiny", model_dir=str(tmp_path), max_batch=2, max_audio_seconds=4, bits=8)
+    ref = OmnilingualASRMLXModel.from_state_dict(expect, variant="tiny", max_batch=2, max_audio_seconds=4, bits=8)
+    try:
+        pcm = _wave(2, 3.0)
+        ids = m.transcribe_batch([pcm])[0]
+        assert ids == ref.transcribe_batch([pcm])[0]
+        assert np.array_equal(m.logits(pcm), ref.logits(pcm))
+        assert m.transcribe_audio(pcm) == O.vocab_decode(ids, pieces)
+    finally:
+        m.close()
+        ref.close()
