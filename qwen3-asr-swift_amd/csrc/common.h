@@ -82,6 +82,15 @@ __device__ __forceinline__ float lane_sum(float p) {
     return p;
 }
 
+// maximum over aligned groups of 16 adjacent lanes, on every lane of the group (same DPP steps)
+__device__ __forceinline__ float lane_max16(float p) {
+    p = fmaxf(p, dpp_mov_f32<0xB1>(p));
+    p = fmaxf(p, dpp_mov_f32<0x4E>(p));
+    p = fmaxf(p, dpp_mov_f32<0x141>(p));
+    p = fmaxf(p, dpp_mov_f32<0x140>(p));
+    return p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -273,8 +273,7 @@ __global__ __launch_bounds__(256) void mha_attention_kernel(const bf16_t* __rest
         float alpha[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int ofs = 1; ofs < 16; ofs <<= 1) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], ofs, 64));
+            mx[j] = lane_max16(mx[j]);
             const float mn = fmaxf(m_run[j], mx[j]);          // finite: every tile below L holds a valid key
             alpha[j] = __expf(m_run[j] - mn);
             m_run[j] = mn;
@@ -290,8 +289,7 @@ __global__ __launch_bounds__(256) void mha_attention_kernel(const bf16_t* __rest
             }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int ofs = 1; ofs < 16; ofs <<= 1) rs[j] += __shfl_xor(rs[j], ofs, 64);
+            rs[j] = lane_sum<16>(rs[j]);
             l_run[j] = l_run[j] * alpha[j] + rs[j];
         }
 #pragma unroll
