@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--ab", default="", help="knob=v1,v2,...: repeat the timed region per value of one tuning knob")
     a = ap.parse_args()
     m = OmnilingualASRMLXModel(variant=a.variant, max_batch=a.batch, max_audio_seconds=int(np.ceil(a.seconds)))
     cfg = m.cfg
@@ -58,6 +59,16 @@ def main():
     m._check(m.lib.qasr_ctc_finalize(m.h))
     print(f"[bench_ctc] weights built + uploaded in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
     clips = [synth.synth_waveform(k, a.seconds) for k in range(a.batch)]
+    if a.ab:
+        key, vals = a.ab.split("=")
+        for v in vals.split(","):
+            m.lib.qasr_set_tuning(key.encode(), int(v))
+            m.transcribe_batch(clips)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                m.transcribe_batch(clips)
+            dt = (time.perf_counter() - t0) / a.steps
+            print(f"[bench_ctc] {key}={v}: {dt * 1e3:.2f} ms/step, stages {[round(x, 2) for x in m.timings()]}", file=sys.stderr, flush=True)
     m.transcribe_batch(clips)                                   # warm-up
     t0 = time.perf_counter()
     for _ in range(a.steps):
