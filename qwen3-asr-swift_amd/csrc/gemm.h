@@ -474,9 +474,20 @@ inline bool gemm_use_glds() {
     return tuning().gemm_glds != 0;
 }
 
+// the 256 x 256 form (gemm_p8.h, included at the end of this header)
+template <class ALoad, class Epi, int MODE>
+__global__ void gemm_nt_p8_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, Epi epi,
+                                  const bf16_t* __restrict__ zeros);
+inline bool gemm_use_p8(int M, int N);
+
 template <class ALoad, class Epi>
 inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
+    if (gemm_use_p8(M, N)) {
+        hipLaunchKernelGGL((gemm_nt_p8_kernel<ALoad, Epi, 0>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), 0, s, a, Wt, ldw, M, N, K,
+                           epi, gemm_zero_block());
+        return;
+    }
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
     if (gemm_use_glds() && gemm_nbuf(grid) == 1)
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
@@ -492,6 +503,11 @@ template <class ALoad, class Epi>
 inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
     if (N % 32 != 0) throw std::invalid_argument("swiglu gemm: fused width must be a multiple of 32");
+    if (gemm_use_p8(M, N)) {
+        hipLaunchKernelGGL((gemm_nt_p8_kernel<ALoad, Epi, 1>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), 0, s, a, Wt, ldw, M, N, K,
+                           epi, gemm_zero_block());
+        return;
+    }
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
     if (gemm_use_glds() && gemm_nbuf(grid) == 1)
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
@@ -542,3 +558,5 @@ struct EpiResidF32 {
 };
 
 }  // namespace qasr
+
+#include "gemm_p8.h"

@@ -1,0 +1,216 @@
+// gemm_p8.h -- the 256 x 256 x 64 form of gemm_nt for launches of many tiles: 8 waves (2 x 4, each 128 x 64), one workgroup
+// per CU, operands by direct-to-LDS loads into a 128 KiB ring that stay in flight across raw barriers.
+//
+// Schedule (MI355X guide, "The 256^2 8-phase template": this is a reconstruction from its description, the choreography
+// below is this file's own and is what has to be checked when it is edited):
+//   * A K-tile (64 wide) is staged as four 16 KiB units of 128 rows: A-lo / A-hi = the first / second 64 rows of each wave
+//     row-group's 128, B-lo / B-hi = the first / second 32 columns of each wave column-group's 64.  Ring = 2 K-tiles x 4 units.
+//   * A K-tile is consumed in four phases, one 64 x 32 quadrant of the wave's output each (16 MFMAs 16x16x32):
+//       P0 reads A-lo (8 fragments) + B-lo (4), quadrant (lo, lo)      P1 reads B-hi (4), quadrant (lo, hi)
+//       P2 reads A-hi (8), quadrant (hi, hi)                           P3 reads nothing, quadrant (hi, lo): B-lo stays in registers
+//     so a unit's last LDS read is P0 (A-lo, B-lo), P1 (B-hi) or P2 (A-hi) of its tile.
+//   * Every phase issues ONE unit (2 direct-to-LDS instructions per wave), always >= 2 phases after the last read of the
+//     slot it overwrites and >= 5 phases before its first read:
+//       P0(t): B-hi(t+1)   P1(t): A-hi(t+1)   P2(t): A-lo(t+2)   P3(t): B-lo(t+2)
+//     and then waits vmcnt(8): everything but the four youngest units has landed, i.e. every unit the NEXT phase reads.
+//   * Phase = [LDS reads, unit issue, vmcnt(8)] s_barrier [lgkmcnt(0), 16 MFMAs] s_barrier.  The wave row-group 1 runs one
+//     barrier behind group 0 (it takes one extra barrier before the loop, group 0 one after it): on every SIMD one wave is in
+//     its MFMA segment while its partner reads LDS.  RAW: a unit is read in phase p + 1 after the vmcnt(8) of phase p of
+//     BOTH groups (intervals 2p and 2p + 1) and the barrier that ends interval 2p + 1.  WAR: a unit issued in phase p (interval
+//     2p at the earliest) overwrites data last read in phase <= p - 2, whose reads retired (lgkmcnt(0)) by interval 2p - 2.
+//   * K-tiles past the end stage zeros (the operand functors return no address for k >= K): the wait counts stay uniform.
+// Epilogue: accumulators through a wave-private LDS image (64 rows x 32 columns per round), rows out as float4.
+#pragma once
+#include "gemm.h"
+
+namespace qasr {
+
+constexpr int P8_BM = 256, P8_BN = 256, P8_THREADS = 512, P8_UNIT = 16384;
+
+template <class ALoad, class Epi, int MODE>
+__global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N,
+                                                                int K, Epi epi, const bf16_t* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) char smem[8 * P8_UNIT];       // [tile parity][A-lo, A-hi, B-lo, B-hi][128 rows x 128 B]
+    constexpr int U_ALO = 0, U_AHI = 1, U_BLO = 2, U_BHI = 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // tiles of one A row panel are consecutive on one XCD (ids go round the 8 XCDs): the panel is fetched into one L2
+    const int nbx = (N + P8_BN - 1) / P8_BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / nbx) * P8_BM, n0 = (bid % nbx) * P8_BN;
+
+    // staging: wave w, instruction i covers unit rows (2 w + i) * 8 .. + 7; lane -> (row + lane / 8, LDS slot lane % 8)
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;                   // source chunk = slot ^ (row & 7)
+    typename ALoad::Row alo[2], ahi[2];
+    const bf16_t *blo[2], *bhi[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = (wave * 2 + i) * 8 + srow;
+        const int am = m0 + (u >> 6) * 128 + (u & 63);
+        alo[i] = aload.row_init(am);
+        ahi[i] = aload.row_init(am + 64);
+        const int bn = n0 + (u >> 5) * 64 + (u & 31);
+        blo[i] = bn < N ? Wt + (long)bn * ldw : nullptr;
+        bhi[i] = bn + 32 < N ? Wt + (long)(bn + 32) * ldw : nullptr;
+    }
+    auto stage_a = [&](int unit, int kt, const typename ALoad::Row* rows) {
+        const int k = kt * GEMM_BK + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* p = aload.addr(rows[i], k);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(p ? p : zeros), (lds_ptr_t)&smem[((kt & 1) * 4 + unit) * P8_UNIT + (wave * 2 + i) * 1024], 16, 0, 0);
+        }
+    };
+    auto stage_b = [&](int unit, int kt, const bf16_t* const* rows) {
+        const int k = kt * GEMM_BK + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* p = (rows[i] && k < K) ? rows[i] + k : nullptr;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(p ? p : zeros), (lds_ptr_t)&smem[((kt & 1) * 4 + unit) * P8_UNIT + (wave * 2 + i) * 1024], 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
+    const int fr = lane & 15, fc = lane >> 4;
+    // fragment byte offsets inside a unit (K-step s adds chunk 4 s: the XOR swizzle keeps bit 2 of the chunk, so + 64 B)
+    int a_off[4], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[i] = gemm_lds_off(wr * 64 + i * 16 + fr, fc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_off[j] = gemm_lds_off(wc * 32 + j * 16 + fr, fc);
+
+    stage_a(U_ALO, 0, alo);
+    stage_b(U_BLO, 0, blo);
+    stage_b(U_BHI, 0, bhi);
+    stage_a(U_AHI, 0, ahi);
+    stage_a(U_ALO, 1, alo);
+    stage_b(U_BLO, 1, blo);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
+
+    mfma_bf16x8 af[4][2], bl[2][2], bh[2][2];
+#define P8_READ_A(UNIT)                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s = 0; s < 2; ++s)                               \
+        af[i][s] = *reinterpret_cast<const mfma_bf16x8*>(&tile[(UNIT) * P8_UNIT + (a_off[i] ^ (s << 6))]);
+#define P8_READ_B(DST, UNIT)                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s)                               \
+        DST[j][s] = *reinterpret_cast<const mfma_bf16x8*>(&tile[(UNIT) * P8_UNIT + (b_off[j] ^ (s << 6))]);
+#define P8_SYNC_IN()                                                                                                         \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    __builtin_amdgcn_s_setprio(1);
+#define P8_MFMA(BF, MH, NH)                                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll")             \
+        for (int j = 0; j < 2; ++j) acc[(MH) * 4 + i][(NH) * 2 + j] =                                                        \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][s], BF[j][s], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);
+#define P8_SYNC_OUT()                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* tile = &smem[(kt & 1) * 4 * P8_UNIT];
+        // P0
+        P8_READ_B(bl, U_BLO)
+        P8_READ_A(U_ALO)
+        stage_b(U_BHI, kt + 1, bhi);
+        P8_SYNC_IN()
+        P8_MFMA(bl, 0, 0)
+        P8_SYNC_OUT()
+        // P1
+        P8_READ_B(bh, U_BHI)
+        stage_a(U_AHI, kt + 1, ahi);
+        P8_SYNC_IN()
+        P8_MFMA(bh, 0, 1)
+        P8_SYNC_OUT()
+        // P2
+        P8_READ_A(U_AHI)
+        stage_a(U_ALO, kt + 2, alo);
+        P8_SYNC_IN()
+        P8_MFMA(bh, 1, 1)
+        P8_SYNC_OUT()
+        // P3
+        stage_b(U_BLO, kt + 2, blo);
+        P8_SYNC_IN()
+        P8_MFMA(bl, 1, 0)
+        P8_SYNC_OUT()
+    }
+#undef P8_READ_A
+#undef P8_READ_B
+#undef P8_SYNC_IN
+#undef P8_MFMA
+#undef P8_SYNC_OUT
+    if (wr == 0) __builtin_amdgcn_s_barrier();              // the groups meet again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero-filled units of K-tiles past the end
+    __builtin_amdgcn_s_barrier();
+
+    // epilogue: four rounds (64-row half, 32-column half) through this wave's 64 x 36-float image
+    constexpr int LDC = 36;
+    float* ct = reinterpret_cast<float*>(smem) + wave * (64 * LDC);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();                // the previous round's reads are done
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * LDC + jj * 16 + fr] = acc[mh * 4 + i][nh * 2 + jj][r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int mb = m0 + wr * 128 + mh * 64, nb = n0 + wc * 64 + nh * 32;
+            if (MODE == 0) {
+                const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll 4
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 8 + er;
+                    if (mb + row < M && nb + ec < N) epi(mb + row, nb + ec, *reinterpret_cast<const float4*>(&ct[row * LDC + ec]));
+                }
+            } else {
+                const int er = lane >> 2, e = (lane & 3) * 4;
+#pragma unroll 4
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 16 + er;
+                    if (mb + row < M && nb < N) {
+                        const float4 g = *reinterpret_cast<const float4*>(&ct[row * LDC + e]);
+                        const float4 u = *reinterpret_cast<const float4*>(&ct[row * LDC + 16 + e]);
+                        float4 v;
+                        v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
+                        v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
+                        epi(mb + row, nb / 2 + e, v);
+                    }
+                }
+            }
+        }
+}
+
+// The 256^2 form pays when the launch fills the chip several times over with little tail: >= 3 rounds of 256 tiles at >= 85 %
+// of the last round used, or >= 8 rounds.  tuning knob gemm_p8: 0 never | 1 by this rule | 2 whenever the shape allows.
+inline bool gemm_use_p8(int M, int N) {
+    const int v = tuning().gemm_p8;
+    if (v == 0 || !gemm_use_glds()) return false;
+    const long tiles = (long)cdiv(M, P8_BM) * cdiv(N, P8_BN);
+    if (v == 2) return true;
+    const long rounds = (tiles + 255) / 256;
+    return rounds >= 8 || (rounds >= 3 && tiles * 100 >= rounds * 256 * 85);
+}
+
+}  // namespace qasr

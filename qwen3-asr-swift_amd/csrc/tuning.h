@@ -17,6 +17,7 @@ struct Tuning {
     int pa_mt = 1;           // row tiles per wave of the first form
     int qknr_wide = 1;       // q/k norm + RoPE of the prompt pass: 16-byte accesses
     int mha_form = 1;        // Omnilingual attention at head_dim 64: 1 | 2 transposed scores on 32x32x16 MFMAs, 128 | 256 queries per workgroup; 0 16x16x32 form
+    int gemm_p8 = 1;         // 256 x 256 ping-pong GEMM form: 0 never | 1 for launches of many tiles | 2 always
     int gemm_nbuf = 0;       // GEMM LDS buffers: 0 auto (by tile count) | 1 | 2
     int gemm_glds = 1;       // GEMM operand staging: 1 direct-to-LDS | 0 through registers
     int lmh_grid = 256;      // persistent LM-head workgroups (read at qasr_finalize: sizes the argmax partials)

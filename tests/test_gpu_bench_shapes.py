@@ -111,6 +111,15 @@ def test_gemm_forms_agree_bit_for_bit(rig):
         finally:
             eng.set_tuning("gemm_nbuf", 0)
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # the 256 x 256 ping-pong form (gemm_p8.h; picked by tile count at 32 clips, forced onto every launch here, ragged
+    # M / N edges and the implicit-conv gathers included) keeps that k order too
+    eng.set_tuning("gemm_p8", 2)
+    try:
+        emb = eng.encode(rig["mel"])
+        p8 = (emb, eng.prefill_logits(emb))
+    finally:
+        eng.set_tuning("gemm_p8", 1)
+    assert np.array_equal(outs[0][0], p8[0]) and np.array_equal(outs[0][1], p8[1])
 
 
 def test_32x30s_shard(rig):

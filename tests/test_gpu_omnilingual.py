@@ -173,6 +173,31 @@ def test_attention_forms_agree_at_head_dim_64():
         m.close()
 
 
+def test_gemm_forms_agree_bit_for_bit():
+    """Every GEMM of the path (conv feature extractor through row tables, projection, grouped positional conv, q|k|v, o, FFN,
+    CTC head with its ragged 10288 columns) on the 128 x 128 forms and on the 256 x 256 ping-pong form (gemm_p8.h): each
+    output is summed in the same k order, so the logits must be the same bits."""
+    cfg = dataclasses.replace(O.VARIANTS["300M"], layers=2)
+    sd = synth.synth_omnilingual_state_dict(cfg, seed=7)
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="300M", layers=2, max_batch=4, max_audio_seconds=12)
+    try:
+        pcm = _wave(2, 11.0)
+        out = []
+        for p8 in (0, 2, 1):
+            m.lib.qasr_set_tuning(b"gemm_p8", p8)
+            out.append(m.logits(pcm))
+        assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+        clips = [_wave(k, 0.9 + 2.3 * k) for k in range(4)]
+        m.lib.qasr_set_tuning(b"gemm_p8", 0)
+        a = m.transcribe_batch(clips)
+        m.lib.qasr_set_tuning(b"gemm_p8", 2)
+        assert m.transcribe_batch(clips) == a
+        _check_logits(m, sd, cfg, pcm, "300M-width, gemm_p8=2")
+    finally:
+        m.lib.qasr_set_tuning(b"gemm_p8", 1)
+        m.close()
+
+
 def test_safetensors_directory_with_sentencepiece(tmp_path):
     """model.safetensors (f16 floats + uint32 triplets, as published) + tokenizer.model (SentencePiece protobuf) through
     qasr_ctc_create == the same tensors through qasr_ctc_set_tensor."""
