@@ -77,8 +77,14 @@ __device__ __forceinline__ float lane_sum(float p) {
     static_assert(N == 8 || N == 16 || N == 32 || N == 64, "group size");
     p = lane_sum8(p);
     if constexpr (N >= 16) p += dpp_mov_f32<0x140>(p);
-    if constexpr (N >= 32) p += __shfl_xor(p, 16, 64);
-    if constexpr (N >= 64) p += __shfl_xor(p, 32, 64);
+    if constexpr (N >= 32) {                   // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+        p = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if constexpr (N >= 64) {                   // v_permlane32_swap: upper half of the first operand <-> lower half of the second
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+        p = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return p;
 }
 
@@ -102,8 +108,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact (erf) GELU, as MLXNN.gelu / torch F.gelu
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-form GELU, as MLXNN.gelu / torch F.gelu: x * Phi(x) with Phi(x) = erfc(-x / sqrt 2) / 2.  erfc(z), z >= 0, by
+// Abramowitz & Stegun 7.1.26 (t = 1 / (1 + p z), five-term polynomial times exp(-z^2); |error| <= 1.5e-7, i.e. f32 rounding
+// class) -- 16 vector instructions where the library erff costs 34 with both of its branches live in a wave; the GELU
+// epilogues of the FFN GEMMs are vector-ALU-bound, not MFMA-bound.  Absolute error of the result <= 0.5 |x| 1.5e-7.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    return 0.5f * x * (x >= 0.f ? 2.0f - erfc_z : erfc_z);
+}
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -80,10 +80,72 @@ __global__ void w2v_conv0_kernel(const float* __restrict__ pcm, const long* __re
     }
 }
 
+// The published geometry (C = 512): a WAVE owns whole frames, a lane 8 consecutive channels (80 weights in registers), so
+// the LayerNorm statistics are two DPP wave sums and nothing synchronises across waves; the samples of a frame are
+// wave-uniform (scalar loads), one 16-byte store per lane and frame.  Vector-ALU-bound by the GELU (16 instructions per
+// element, 1.6 G elements at 32 x 30 s).
+constexpr int CONV0W_FPW = 16, CONV0W_WAVES = 4;
+
+__global__ __launch_bounds__(CONV0W_WAVES * 64) void w2v_conv0_wave_kernel(
+    const float* __restrict__ pcm, const long* __restrict__ pcm_off, const float* __restrict__ stats, const int* __restrict__ frame_off,
+    const int* __restrict__ n_out, const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ ln_g,
+    const float* __restrict__ ln_b, float eps, bf16_t* __restrict__ out) {
+    constexpr int C = 512, CPL = 8;
+    const int b = blockIdx.y, nf = n_out[b];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int f0 = (blockIdx.x * CONV0W_WAVES + wave) * CONV0W_FPW;
+    if (f0 >= nf) return;
+    const int f1 = f0 + CONV0W_FPW < nf ? f0 + CONV0W_FPW : nf;
+    float wk[CPL][10], bc[CPL], g[CPL], be[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = lane * CPL + j;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) wk[j][k] = w[c * 10 + k];
+        bc[j] = bias[c]; g[j] = ln_g[c]; be[j] = ln_b[c];
+    }
+    const float mean = stats[2 * b], inv = stats[2 * b + 1];
+    const float* x = pcm + pcm_off[b];
+    bf16_t* dst = out + ((long)frame_off[b] + f0) * C + lane * CPL;
+    float xs[10];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xs[5 + k] = (x[(long)f0 * 5 + k] - mean) * inv;
+    for (int f = f0; f < f1; ++f, dst += C) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { xs[k] = xs[5 + k]; xs[5 + k] = (x[(long)f * 5 + 5 + k] - mean) * inv; }
+        float v[CPL], s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            float a = bc[j];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a = fmaf(wk[j][k], xs[k], a);
+            v[j] = a;
+            s += a;
+            ss = fmaf(a, a, ss);
+        }
+        s = lane_sum<64>(s);
+        ss = lane_sum<64>(ss);
+        const float mu = s * (1.0f / C);
+        const float rstd = rsqrtf(fmaxf(ss * (1.0f / C) - mu * mu, 0.0f) + eps);
+        float y[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) y[j] = gelu_erf((v[j] - mu) * rstd * g[j] + be[j]);
+        uint4 o;
+        const uint2 lo = pack_bf16x4(make_float4(y[0], y[1], y[2], y[3])), hi = pack_bf16x4(make_float4(y[4], y[5], y[6], y[7]));
+        o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+        *reinterpret_cast<uint4*>(dst) = o;
+    }
+}
+
 void w2v_conv0_launch(const float* pcm, const long* pcm_off, const float* stats, const int* frame_off, const int* n_out, int B,
                       int max_out, const float* w, const float* bias, const float* ln_g, const float* ln_b, float eps, bf16_t* out,
                       int C, hipStream_t s) {
     if (B <= 0 || max_out <= 0) return;
+    if (C == 512) {
+        hipLaunchKernelGGL(w2v_conv0_wave_kernel, dim3(cdiv(max_out, CONV0W_FPW * CONV0W_WAVES), B), dim3(CONV0W_WAVES * 64), 0, s, pcm,
+                           pcm_off, stats, frame_off, n_out, w, bias, ln_g, ln_b, eps, out);
+        return;
+    }
     if (C > 1024) throw std::invalid_argument("conv0: at most 1024 channels");
     const int threads = ((C + 63) / 64) * 64;
     const size_t lds = (size_t)(CONV0_FPB * 5 + 8 + 32) * sizeof(float);
