@@ -44,6 +44,7 @@ struct AGroupConv1d {
     const bf16_t* x;        // [frames][D] bf16
     const int2* info;       // per frame (t, L)
     int D, cpg, KP, g, M;
+    static constexpr bool no_p8 = true;   // N = D / 16 columns per launch: a 256-wide tile would be mostly padding anyway
     struct Row { const bf16_t* base; int kmin, kmax; };
     __device__ __forceinline__ Row row_init(int m) const {
         if (m >= M) return {nullptr, 0, 0};
@@ -69,33 +70,40 @@ struct AGroupConv1d {
 // out_f32[m][n] = acc + bias[n]
 struct EpiBiasF32 {
     float* out; long ldo; const float* bias;
-    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    struct Pre { float4 b; };
+    __device__ __forceinline__ Pre prefetch(int m, int n) const { return {*reinterpret_cast<const float4*>(bias + n)}; }
+    __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
+        v.x += p.b.x; v.y += p.b.y; v.z += p.b.z; v.w += p.b.w;
         *reinterpret_cast<float4*>(out + (long)m * ldo + n) = v;
     }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
 };
 // out_bf16[m][n] = act(acc + bias[n]); ACT 0 none, 1 exact GELU
 template <int ACT>
 struct EpiBiasActBf16F {
     bf16_t* out; long ldo; const float* bias;
-    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    struct Pre { float4 b; };
+    __device__ __forceinline__ Pre prefetch(int m, int n) const { return {*reinterpret_cast<const float4*>(bias + n)}; }
+    __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
+        v.x += p.b.x; v.y += p.b.y; v.z += p.b.z; v.w += p.b.w;
         if (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         *reinterpret_cast<uint2*>(out + (long)m * ldo + n) = pack_bf16x4(v);
     }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
 };
 // x_f32[m][n] += acc + bias[n]
 struct EpiResidF32F {
     float* x; long ldx; const float* bias;
-    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        float4* p = reinterpret_cast<float4*>(x + (long)m * ldx + n);
-        float4 r = *p;
-        r.x += v.x + b.x; r.y += v.y + b.y; r.z += v.z + b.z; r.w += v.w + b.w;
-        *p = r;
+    struct Pre { float4 b, r; };
+    __device__ __forceinline__ Pre prefetch(int m, int n) const {
+        return {*reinterpret_cast<const float4*>(bias + n), *reinterpret_cast<const float4*>(x + (long)m * ldx + n)};
     }
+    __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
+        float4 r = p.r;
+        r.x += v.x + p.b.x; r.y += v.y + p.b.y; r.z += v.z + p.b.z; r.w += v.w + p.b.w;
+        *reinterpret_cast<float4*>(x + (long)m * ldx + n) = r;
+    }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
 };
 // positional encoder: y[m][col0 + n] = gelu(acc + bias[col0 + n]) + x[m][col0 + n]
 struct EpiPosConv {

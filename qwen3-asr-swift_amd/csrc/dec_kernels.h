@@ -134,12 +134,14 @@ void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_pa
 // x_bf16[m][n] = bf16(x + bf16(acc))   (residual add in the decoder dtype)
 struct EpiResidBf16 {
     bf16_t* x; long ldx;
-    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
-        bf16_t* p = x + (long)m * ldx + n;
-        float4 r = load_bf16x4(p);
+    struct Pre { uint2 r; };
+    __device__ __forceinline__ Pre prefetch(int m, int n) const { return {*reinterpret_cast<const uint2*>(x + (long)m * ldx + n)}; }
+    __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
+        float4 r = unpack_bf16x4(p.r);
         r.x += bf16_round(v.x); r.y += bf16_round(v.y); r.z += bf16_round(v.z); r.w += bf16_round(v.w);
-        *reinterpret_cast<uint2*>(p) = pack_bf16x4(r);
+        *reinterpret_cast<uint2*>(x + (long)m * ldx + n) = pack_bf16x4(r);
     }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
 };
 
 // QuantizedTextDecoder.swift:134-136 with bf16 tensors: silu(gate) -> bf16, * up -> bf16

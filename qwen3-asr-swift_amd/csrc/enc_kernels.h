@@ -38,15 +38,20 @@ void window_attention_launch(const bf16_t* qkv, const int* cu_seqlens, int n_win
 struct EpiConvGelu {
     bf16_t* out; long ldo; const bf16_t* bias; const ChunkMeta* chunks;
     int OH, OW; bool hw_major; int level;      // level 2 -> w2, 3 -> w3
-    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
-        int img = m / (OH * OW), rem = m - img * (OH * OW);
-        int ow = hw_major ? rem % OW : rem / OH;
-        int wv = level == 2 ? chunks[img].w2 : chunks[img].w3;
-        float4 b = load_bf16x4(bias + n);
+    struct Pre { uint2 b; int wv; };
+    __device__ __forceinline__ Pre prefetch(int m, int n) const {
+        const int img = m / (OH * OW);
+        return {*reinterpret_cast<const uint2*>(bias + n), level == 2 ? chunks[img].w2 : chunks[img].w3};
+    }
+    __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
+        const int img = m / (OH * OW), rem = m - img * (OH * OW);
+        const int ow = hw_major ? rem % OW : rem / OH;
+        const float4 b = unpack_bf16x4(p.b);
         v.x = gelu_erf(v.x + b.x); v.y = gelu_erf(v.y + b.y); v.z = gelu_erf(v.z + b.z); v.w = gelu_erf(v.w + b.w);
-        if (ow >= wv) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ow >= p.wv) v = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<uint2*>(out + (long)m * ldo + n) = pack_bf16x4(v);
     }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
 };
 
 // conv_out: x_f32[token][n] = acc + pe[t_in_chunk(token)][n]   (AudioEncoder.swift:427-439)

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "tuning.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace qasr {
 
@@ -479,13 +480,19 @@ template <class ALoad, class Epi, int MODE>
 __global__ void gemm_nt_p8_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, Epi epi,
                                   const bf16_t* __restrict__ zeros);
 inline bool gemm_use_p8(int M, int N);
+inline int gemm_p8_grid(int M, int N);
+// an A functor may opt out (static constexpr bool no_p8 = true): one whose per-row state does not fit the 256-register budget
+template <class A, class = void>
+struct gemm_p8_allowed { static constexpr bool value = true; };
+template <class A>
+struct gemm_p8_allowed<A, std::void_t<decltype(A::no_p8)>> { static constexpr bool value = !A::no_p8; };
 
 template <class ALoad, class Epi>
 inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
     if (M <= 0 || N <= 0) return;
-    if (gemm_use_p8(M, N)) {
-        hipLaunchKernelGGL((gemm_nt_p8_kernel<ALoad, Epi, 0>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), 0, s, a, Wt, ldw, M, N, K,
-                           epi, gemm_zero_block());
+    if constexpr (gemm_p8_allowed<ALoad>::value) if (gemm_use_p8(M, N)) {
+        hipLaunchKernelGGL((gemm_nt_p8_kernel<ALoad, Epi, 0>), dim3(gemm_p8_grid(M, N)), dim3(512), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block());
         return;
     }
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
@@ -504,8 +511,8 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
     if (M <= 0 || N <= 0) return;
     if (N % 32 != 0) throw std::invalid_argument("swiglu gemm: fused width must be a multiple of 32");
     if (gemm_use_p8(M, N)) {
-        hipLaunchKernelGGL((gemm_nt_p8_kernel<ALoad, Epi, 1>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), 0, s, a, Wt, ldw, M, N, K,
-                           epi, gemm_zero_block());
+        hipLaunchKernelGGL((gemm_nt_p8_kernel<ALoad, Epi, 1>), dim3(gemm_p8_grid(M, N)), dim3(512), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block());
         return;
     }
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
@@ -521,12 +528,24 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
 
 // ------------------------------------------------------------------------------------------------
 // epilogues: operator()(m, n, float4 acc[n..n+3])   (N is always a multiple of 4)
+// Optional split form for kernels that run one workgroup per CU and cannot hide an epilogue's global loads behind other
+// workgroups (gemm_p8.h): a nested type Pre, `Pre prefetch(m, n)` = the loads only, `apply(m, n, acc, pre)` = the rest;
+// operator() == apply(prefetch).  The caller issues the prefetch of the next output rows before it applies the current ones.
 // ------------------------------------------------------------------------------------------------
+template <class E, class = void>
+struct epi_has_pre { static constexpr bool value = false; };
+template <class E>
+struct epi_has_pre<E, std::void_t<typename E::Pre>> { static constexpr bool value = true; };
+
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     uint2 o;
     o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
     o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
     return o;
+}
+__device__ __forceinline__ float4 unpack_bf16x4(uint2 u) {
+    return make_float4(bf16_to_f32((bf16_t)(u.x & 0xffff)), bf16_to_f32((bf16_t)(u.x >> 16)),
+                       bf16_to_f32((bf16_t)(u.y & 0xffff)), bf16_to_f32((bf16_t)(u.y >> 16)));
 }
 __device__ __forceinline__ float4 load_bf16x4(const bf16_t* p) {
     uint2 u = *reinterpret_cast<const uint2*>(p);
@@ -538,23 +557,33 @@ __device__ __forceinline__ float4 load_bf16x4(const bf16_t* p) {
 template <int ACT>
 struct EpiBiasActBf16 {
     bf16_t* out; long ldo; const bf16_t* bias;   // bias may be null
-    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
-        if (bias) { float4 b = load_bf16x4(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    struct Pre { uint2 b; };
+    __device__ __forceinline__ Pre prefetch(int m, int n) const {
+        return {bias ? *reinterpret_cast<const uint2*>(bias + n) : make_uint2(0u, 0u)};
+    }
+    __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
+        const float4 b = unpack_bf16x4(p.b);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         if (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         *reinterpret_cast<uint2*>(out + (long)m * ldo + n) = pack_bf16x4(v);
     }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
 };
 
 // x_f32[m][n] += acc + bias[n]   (encoder residual stream, f32)
 struct EpiResidF32 {
     float* x; long ldx; const bf16_t* bias;
-    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
-        float4 b = load_bf16x4(bias + n);
-        float4* p = reinterpret_cast<float4*>(x + (long)m * ldx + n);
-        float4 r = *p;
-        r.x += v.x + b.x; r.y += v.y + b.y; r.z += v.z + b.z; r.w += v.w + b.w;
-        *p = r;
+    struct Pre { uint2 b; float4 r; };
+    __device__ __forceinline__ Pre prefetch(int m, int n) const {
+        return {*reinterpret_cast<const uint2*>(bias + n), *reinterpret_cast<const float4*>(x + (long)m * ldx + n)};
     }
+    __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
+        const float4 b = unpack_bf16x4(p.b);
+        float4 r = p.r;
+        r.x += v.x + b.x; r.y += v.y + b.y; r.z += v.z + b.z; r.w += v.w + b.w;
+        *reinterpret_cast<float4*>(x + (long)m * ldx + n) = r;
+    }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
 };
 
 }  // namespace qasr

@@ -19,13 +19,20 @@
 //     BOTH groups (intervals 2p and 2p + 1) and the barrier that ends interval 2p + 1.  WAR: a unit issued in phase p (interval
 //     2p at the earliest) overwrites data last read in phase <= p - 2, whose reads retired (lgkmcnt(0)) by interval 2p - 2.
 //   * K-tiles past the end stage zeros (the operand functors return no address for k >= K): the wait counts stay uniform.
-// Epilogue: accumulators through a wave-private LDS image (64 rows x 32 columns per round), rows out as float4.
+//   * Workgroups are persistent (one per CU): when a tile's K loop ends, the first K-tile of the workgroup's NEXT tile is issued
+//     into the parity-0 half of the ring before the epilogue, which stages the accumulators through the parity-1 half
+//     (wave-private 32 x 32 images, rows out as float4): the next tile's first-load latency hides under the epilogue.
 #pragma once
 #include "gemm.h"
 
 namespace qasr {
 
 constexpr int P8_BM = 256, P8_BN = 256, P8_THREADS = 512, P8_UNIT = 16384;
+
+template <class E, bool HAS>
+struct epi_pre_type { struct type {}; };
+template <class E>
+struct epi_pre_type<E, true> { using type = typename E::Pre; };
 
 template <class ALoad, class Epi, int MODE>
 __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N,
@@ -35,30 +42,37 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    // tiles of one A row panel are consecutive on one XCD (ids go round the 8 XCDs): the panel is fetched into one L2
-    const int nbx = (N + P8_BN - 1) / P8_BN;
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int m0 = (bid / nbx) * P8_BM, n0 = (bid % nbx) * P8_BN;
+    // Persistent workgroups (one per CU).  Workgroup ids go round the 8 XCDs, so id & 7 names the XCD; XCD x owns the x-th
+    // eighth of the tile list (column tile fastest) and its workgroups walk that range round-robin: the tiles in flight on one
+    // XCD share one or two A row panels (fetched into that L2 once) and all of W.
+    const int nbx = (N + P8_BN - 1) / P8_BN, nby = (M + P8_BM - 1) / P8_BM;
+    const int ncls = gridDim.x < 8 ? gridDim.x : 8;         // a launch of fewer than 8 workgroups: one tile range each
+    const int xcd = blockIdx.x % ncls, wgs_per_xcd = (gridDim.x - xcd + ncls - 1) / ncls;
+    const long n_tiles = (long)nbx * nby;
+    const int t_end = (int)(n_tiles * (xcd + 1) / ncls);
+    int lt = (int)(n_tiles * xcd / ncls) + blockIdx.x / ncls;   // this workgroup's tile
+    if (lt >= t_end) return;
 
     // staging: wave w, instruction i covers unit rows (2 w + i) * 8 .. + 7; lane -> (row + lane / 8, LDS slot lane % 8)
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;                   // source chunk = slot ^ (row & 7)
     typename ALoad::Row alo[2], ahi[2];
     const bf16_t *blo[2], *bhi[2];
+    int m0, n0;
+    auto tile_rows = [&](int t) {
+        m0 = (t / nbx) * P8_BM;
+        n0 = (t % nbx) * P8_BN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = (wave * 2 + i) * 8 + srow;
-        const int am = m0 + (u >> 6) * 128 + (u & 63);
-        alo[i] = aload.row_init(am);
-        ahi[i] = aload.row_init(am + 64);
-        const int bn = n0 + (u >> 5) * 64 + (u & 31);
-        blo[i] = bn < N ? Wt + (long)bn * ldw : nullptr;
-        bhi[i] = bn + 32 < N ? Wt + (long)(bn + 32) * ldw : nullptr;
-    }
+        for (int i = 0; i < 2; ++i) {
+            const int u = (wave * 2 + i) * 8 + srow;
+            const int am = m0 + (u >> 6) * 128 + (u & 63);
+            alo[i] = aload.row_init(am);
+            ahi[i] = aload.row_init(am + 64);
+            const int bn = n0 + (u >> 5) * 64 + (u & 31);
+            blo[i] = bn < N ? Wt + (long)bn * ldw : nullptr;
+            bhi[i] = bn + 32 < N ? Wt + (long)(bn + 32) * ldw : nullptr;
+        }
+    };
     auto stage_a = [&](int unit, int kt, const typename ALoad::Row* rows) {
         const int k = kt * GEMM_BK + schunk * 8;
 #pragma unroll
@@ -75,12 +89,12 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(p ? p : zeros), (lds_ptr_t)&smem[((kt & 1) * 4 + unit) * P8_UNIT + (wave * 2 + i) * 1024], 16, 0, 0);
         }
     };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage_first = [&]() {                              // K-tile 0 of a tile: the parity-0 half of the ring
+        stage_a(U_ALO, 0, alo);
+        stage_b(U_BLO, 0, blo);
+        stage_b(U_BHI, 0, bhi);
+        stage_a(U_AHI, 0, ahi);
+    };
 
     const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
     const int fr = lane & 15, fc = lane >> 4;
@@ -91,10 +105,16 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
 #pragma unroll
     for (int j = 0; j < 2; ++j) b_off[j] = gemm_lds_off(wc * 32 + j * 16 + fr, fc);
 
-    stage_a(U_ALO, 0, alo);
-    stage_b(U_BLO, 0, blo);
-    stage_b(U_BHI, 0, bhi);
-    stage_a(U_AHI, 0, ahi);
+    tile_rows(lt);
+    stage_first();
+  for (;;) {
+    const int cm0 = m0, cn0 = n0;                           // this tile's origin (tile_rows moves on before the epilogue)
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     stage_a(U_ALO, 1, alo);
     stage_b(U_BLO, 1, blo);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -159,47 +179,89 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero-filled units of K-tiles past the end
     __builtin_amdgcn_s_barrier();
 
-    // epilogue: four rounds (64-row half, 32-column half) through this wave's 64 x 36-float image
+    // next tile: its first K-tile goes to the parity-0 half of the ring now, in flight under this tile's epilogue
+    lt += wgs_per_xcd;
+    const bool more = lt < t_end;
+    if (more) {
+        tile_rows(lt);
+        stage_first();
+    }
+    // epilogue: eight rounds (64-row half, 32-column half, 32-row half) through this wave's 32 x 36-float image in the
+    // parity-1 half of the ring
     constexpr int LDC = 36;
-    float* ct = reinterpret_cast<float*>(smem) + wave * (64 * LDC);
+    float* ct = reinterpret_cast<float*>(smem + 4 * P8_UNIT) + wave * (32 * LDC);
+    constexpr bool PRE = MODE == 0 && epi_has_pre<Epi>::value;
+    const int er0 = lane >> 3, ec0 = (lane & 7) * 4;        // MODE 0 read-back map: row it * 8 + er0, columns ec0 .. + 3
+    auto round_base = [&](int rd, int& mb, int& nb) {       // round rd = (mh, nh, rh)
+        mb = cm0 + wr * 128 + (rd >> 2) * 64 + (rd & 1) * 32;
+        nb = cn0 + wc * 64 + ((rd >> 1) & 1) * 32;
+    };
+    // the epilogue's own global loads (bias, residual rows) of round rd + 1 are requested before round rd is applied
+    auto prefetch_round = [&](int rd, auto& dst) {
+        if constexpr (PRE) {
+            int mb, nb;
+            round_base(rd, mb, nb);
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
+            for (int it = 0; it < 4; ++it) {
+                const int m = mb + it * 8 + er0, n = nb + ec0;
+                if (m < M && n < N) dst[it] = epi.prefetch(m, n);
+            }
+        }
+    };
+    struct NoPre {};
+    using PreT = typename std::conditional<PRE, typename epi_pre_type<Epi, PRE>::type, NoPre>::type;
+    PreT pre[4] = {}, nxt[4] = {};
+    prefetch_round(0, pre);
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();                // the previous round's reads are done
+    for (int rd = 0; rd < 8; ++rd) {
+        const int mh = rd >> 2, nh = (rd >> 1) & 1, rh = rd & 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                    // the previous round's reads are done
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * LDC + jj * 16 + fr] = acc[mh * 4 + i][nh * 2 + jj][r];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int mb = m0 + wr * 128 + mh * 64, nb = n0 + wc * 64 + nh * 32;
-            if (MODE == 0) {
-                const int er = lane >> 3, ec = (lane & 7) * 4;
-#pragma unroll 4
-                for (int it = 0; it < 8; ++it) {
-                    const int row = it * 8 + er;
-                    if (mb + row < M && nb + ec < N) epi(mb + row, nb + ec, *reinterpret_cast<const float4*>(&ct[row * LDC + ec]));
+                for (int r = 0; r < 4; ++r)
+                    ct[(i * 16 + fc * 4 + r) * LDC + jj * 16 + fr] = acc[mh * 4 + rh * 2 + i][nh * 2 + jj][r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int mb, nb;
+        round_base(rd, mb, nb);
+        if (MODE == 0) {
+            float4 v[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const float4*>(&ct[(it * 8 + er0) * LDC + ec0]);
+            if (rd < 7) prefetch_round(rd + 1, nxt);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = mb + it * 8 + er0, n = nb + ec0;
+                if (m < M && n < N) {
+                    if constexpr (PRE) epi.apply(m, n, v[it], pre[it]);
+                    else epi(m, n, v[it]);
                 }
-            } else {
-                const int er = lane >> 2, e = (lane & 3) * 4;
-#pragma unroll 4
-                for (int it = 0; it < 4; ++it) {
-                    const int row = it * 16 + er;
-                    if (mb + row < M && nb < N) {
-                        const float4 g = *reinterpret_cast<const float4*>(&ct[row * LDC + e]);
-                        const float4 u = *reinterpret_cast<const float4*>(&ct[row * LDC + 16 + e]);
-                        float4 v;
-                        v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
-                        v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
-                        epi(mb + row, nb / 2 + e, v);
-                    }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) pre[it] = nxt[it];
+        } else {
+            const int er = lane >> 2, e = (lane & 3) * 4;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 16 + er;
+                if (mb + row < M && nb < N) {
+                    const float4 g = *reinterpret_cast<const float4*>(&ct[row * LDC + e]);
+                    const float4 u = *reinterpret_cast<const float4*>(&ct[row * LDC + 16 + e]);
+                    float4 v;
+                    v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
+                    v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
+                    epi(mb + row, nb / 2 + e, v);
                 }
             }
         }
+    }
+    if (!more) break;
+    __builtin_amdgcn_s_barrier();                           // every wave is done with its epilogue image: K-tile 1 may land there
+  }
 }
 
 // The 256^2 form pays when the launch fills the chip several times over with little tail: >= 3 rounds of 256 tiles at >= 85 %
@@ -211,6 +273,20 @@ inline bool gemm_use_p8(int M, int N) {
     if (v == 2) return true;
     const long rounds = (tiles + 255) / 256;
     return rounds >= 8 || (rounds >= 3 && tiles * 100 >= rounds * 256 * 85);
+}
+
+// persistent grid: one workgroup per CU (128 KiB of LDS each), fewer when the launch has fewer tiles
+inline int gemm_p8_grid(int M, int N) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        QASR_HIP(hipGetDevice(&dev));
+        QASR_HIP(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long tiles = (long)cdiv(M, P8_BM) * cdiv(N, P8_BN);
+    return (int)(tiles < cus ? tiles : cus);
 }
 
 }  // namespace qasr
