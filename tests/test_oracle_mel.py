@@ -1,8 +1,11 @@
 """Mel oracle: shape contract of the reference tests (Qwen3ASRTests.swift:120-159), edge rules,
 and agreement of the float32 restatement with a float64 re-derivation (<= 1e-4 abs)."""
+import os
 import numpy as np
 import pytest
+from conftest import GOLDEN
 from oracle import mel
+from oracle import mel as M
 from qasr import synth
 
 
@@ -56,3 +59,38 @@ def test_short_input_reflect_clamps():
         assert p.shape[0] == n + 400 and np.isfinite(p).all()
     with pytest.raises(ValueError):
         mel.log_mel(np.zeros(0, np.float32))
+
+
+# ---- pinned by an independent implementation (tests/golden/hf_mel.npz, tests/golden/make_hf_goldens_mel.py) ------------
+_G = np.load(os.path.join(GOLDEN, "hf_mel.npz"))
+
+
+def test_window_and_filterbank_match_transformers_audio_utils():
+    """R1: periodic Hann[400] and the slaney filterbank on the 512-point bin grid vs transformers.audio_utils
+    (window_function / mel_filter_bank with the reference's parameters), float64 there, float32 here."""
+    assert np.abs(M.hann_window() - _G["window"]).max() < 5e-7
+    fb = M.mel_filterbank()
+    assert fb.shape == (128, 257)
+    assert np.abs(fb - _G["filterbank"].T).max() < 1.1e-6                     # 2.5e-5 of the largest weight (0.0424)
+
+
+@pytest.mark.parametrize("name", ["synth", "speech", "short"])
+def test_log_mel_matches_transformers_spectrogram(name):
+    """R2 at the textbook FFT scale: reflect pad, 400-sample frames zero-padded to 512, power, mel, floor, log10 from the
+    library's generic STFT (float64), then the reference's own tail in the reference's order -- max over ALL frames
+    including the dropped one, clamp max - 8, * 0.25 + 1, drop the last frame (AudioPreprocessing.swift:283-296).
+    What this does NOT pin: the Accelerate 2x FFT convention (fft_scale = 2.0), a constant +log10(4) before the clamp."""
+    pcm, raw = _G["wave/" + name], _G["raw_log10/" + name].astype(np.float64)
+    assert raw.shape == (128, M.num_frames(len(pcm)))
+    want = (np.maximum(raw, raw.max() - 8.0) * 0.25 + 1.0)[:, :-1]
+    got = M.log_mel(pcm, fft_scale=1.0)
+    assert got.shape == want.shape
+    err = np.abs(got - want).max()
+    print(f"{name}: max |oracle - transformers| = {err:.2e}")
+    assert err < 1e-4
+    # and the 2x variant is that spectrum shifted by log10(4) before the clamp, wherever the 1e-10 floor is not active
+    # (the speech slice starts in digital silence: floored bins do not shift)
+    raw2 = np.where(raw > -10.0 + 1e-9, raw + np.log10(4.0), np.maximum(raw, -10.0))
+    want2 = (np.maximum(raw2, raw2.max() - 8.0) * 0.25 + 1.0)[:, :-1]
+    live = (raw > -9.0)[:, :-1]
+    assert np.abs(M.log_mel(pcm, fft_scale=2.0) - want2)[live].max() < 1e-4
