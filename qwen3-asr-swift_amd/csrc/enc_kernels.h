@@ -20,7 +20,7 @@ struct ChunkMeta {
 // ---- conv2d1: [img][128][w0] f32 (from the per-clip [128][stride] mel) -> NHWC bf16 [img][H1][W1][C]
 // out = gelu(bias + sum_{kh,kw} w[c][kh][kw] * in(2oh-1+kh, 2ow-1+kw)), f32 arithmetic.
 void conv1_launch(const float* mel, int mel_stride, int n_mels, const ChunkMeta* chunks, int n_img,
-                  const bf16_t* w /*[C][3][3][1]*/, const bf16_t* bias, bf16_t* out, int H1, int W1, int C,
+                  const bf16_t* w /*[C][3][3][1]*/, const float* bias, bf16_t* out, int H1, int W1, int C,
                   hipStream_t s);
 
 // ---- LayerNorm over the last dim: x f32 [T][D] -> y bf16 [T][D] (eps, affine bf16 params)
@@ -36,17 +36,17 @@ void window_attention_launch(const bf16_t* qkv, const int* cu_seqlens, int n_win
 // ---- epilogues used only by the encoder ---------------------------------------------------------
 // conv2/conv3: out = gelu(acc + bias) as bf16, zero beyond the image's valid output width
 struct EpiConvGelu {
-    bf16_t* out; long ldo; const bf16_t* bias; const ChunkMeta* chunks;
+    bf16_t* out; long ldo; const float* bias; const ChunkMeta* chunks;
     int OH, OW; bool hw_major; int level;      // level 2 -> w2, 3 -> w3
-    struct Pre { uint2 b; int wv; };
+    struct Pre { float4 b; int wv; };
     __device__ __forceinline__ Pre prefetch(int m, int n) const {
         const int img = m / (OH * OW);
-        return {*reinterpret_cast<const uint2*>(bias + n), level == 2 ? chunks[img].w2 : chunks[img].w3};
+        return {*reinterpret_cast<const float4*>(bias + n), level == 2 ? chunks[img].w2 : chunks[img].w3};
     }
     __device__ __forceinline__ void apply(int m, int n, float4 v, const Pre& p) const {
         const int img = m / (OH * OW), rem = m - img * (OH * OW);
         const int ow = hw_major ? rem % OW : rem / OH;
-        const float4 b = unpack_bf16x4(p.b);
+        const float4 b = p.b;
         v.x = gelu_erf(v.x + b.x); v.y = gelu_erf(v.y + b.y); v.z = gelu_erf(v.z + b.z); v.w = gelu_erf(v.w + b.w);
         if (ow >= p.wv) v = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<uint2*>(out + (long)m * ldo + n) = pack_bf16x4(v);

@@ -9,7 +9,7 @@ namespace qasr {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ mel, int mel_stride, int n_mels,
                                                     const ChunkMeta* __restrict__ chunks, const bf16_t* __restrict__ w,
-                                                    const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                    const float* __restrict__ bias, bf16_t* __restrict__ out,
                                                     int H1, int W1, int C) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_in = sm;                 // [3][W_IN + 2], column 0 = iw -1
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
         int t = i / C, c = i - t * C;
         s_w[i] = bf16_to_f32(w[c * 9 + t]);
     }
-    for (int i = tid; i < C; i += 256) s_b[i] = bf16_to_f32(bias[i]);
+    for (int i = tid; i < C; i += 256) s_b[i] = bias[i];
     __syncthreads();
     const int P = C / 8, G = 256 / P;
     const int g = tid / P, c0 = (tid - g * P) * 8;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
 }
 
 void conv1_launch(const float* mel, int mel_stride, int n_mels, const ChunkMeta* chunks, int n_img, const bf16_t* w,
-                  const bf16_t* bias, bf16_t* out, int H1, int W1, int C, hipStream_t s) {
+                  const float* bias, bf16_t* out, int H1, int W1, int C, hipStream_t s) {
     if (n_img <= 0) return;
     size_t sh = (3 * (2 * W1 + 2) + 10 * C) * sizeof(float);
     hipLaunchKernelGGL(conv1_kernel, dim3(H1, n_img), dim3(256), sh, s, mel, mel_stride, n_mels, chunks, w, bias, out,

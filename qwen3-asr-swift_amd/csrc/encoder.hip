@@ -11,6 +11,7 @@
 //   h/qkv/a/mid bf16                             LayerNorm out / fused QKV / attention / FFN mid
 //   audio  bf16 [tokens][out_dim]                proj2 output = embeddings spliced into the prompt
 #include "engine.h"
+#include "ctc_kernels.h"   // f32-parameter LayerNorm and GEMM epilogues (shared with the wav2vec2 path)
 #include <cmath>
 #include <cstring>
 
@@ -45,17 +46,35 @@ const bf16_t* Engine::wptr(const std::string& name, std::initializer_list<int64_
     return t.buf.as<bf16_t>();
 }
 
+__global__ void widen_vec_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = bf16_to_f32(src[i]);
+}
+
+const float* Engine::fvec(const std::string& name, int64_t n) {
+    const Tensor& t = tensor(name);
+    if (t.shape != std::vector<int64_t>{n}) throw std::runtime_error("tensor " + name + ": unexpected shape");
+    if (t.dtype == QASR_DTYPE_F32) return t.buf.as<float>();
+    if (t.dtype != QASR_DTYPE_BF16) throw std::runtime_error("tensor " + name + ": expected bf16 or f32");
+    auto buf = std::make_unique<DevBuf>();
+    buf->alloc((size_t)n * sizeof(float));
+    hipLaunchKernelGGL(widen_vec_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream_, t.buf.as<bf16_t>(), buf->as<float>(), (long)n);
+    const float* p = buf->as<float>();
+    fused_.push_back(std::move(buf));
+    return p;
+}
+
 void Engine::finalize_encoder() {
     const int D = cfg_.enc_d_model, C = cfg_.conv_channels, F = cfg_.enc_ffn;
     H1_ = conv_len(cfg_.n_mels); H2_ = conv_len(H1_); H3_ = conv_len(H2_);
     W1_ = conv_len(2 * cfg_.n_window); W2_ = conv_len(W1_); W3_ = conv_len(W2_);
     const std::string a = "audio_tower.";
     encw_.c1w = wptr(a + "conv2d1.weight", {C, 3, 3, 1});
-    encw_.c1b = wptr(a + "conv2d1.bias", {C});
+    encw_.c1b = fvec(a + "conv2d1.bias", C);
     encw_.c2w = wptr(a + "conv2d2.weight", {C, 3, 3, C});
-    encw_.c2b = wptr(a + "conv2d2.bias", {C});
+    encw_.c2b = fvec(a + "conv2d2.bias", C);
     encw_.c3w = wptr(a + "conv2d3.weight", {C, 3, 3, C});
-    encw_.c3b = wptr(a + "conv2d3.bias", {C});
+    encw_.c3b = fvec(a + "conv2d3.bias", C);
     const bf16_t* co = wptr(a + "conv_out.weight", {D, (int64_t)C * H3_});
     {
         auto buf = std::make_unique<DevBuf>();
@@ -66,43 +85,43 @@ void Engine::finalize_encoder() {
         encw_.conv_out = buf->as<bf16_t>();
         fused_.push_back(std::move(buf));
     }
-    encw_.lnp_g = wptr(a + "ln_post.weight", {D});
-    encw_.lnp_b = wptr(a + "ln_post.bias", {D});
+    encw_.lnp_g = fvec(a + "ln_post.weight", D);
+    encw_.lnp_b = fvec(a + "ln_post.bias", D);
     encw_.p1w = wptr(a + "proj1.weight", {D, D});
-    encw_.p1b = wptr(a + "proj1.bias", {D});
+    encw_.p1b = fvec(a + "proj1.bias", D);
     encw_.p2w = wptr(a + "proj2.weight", {cfg_.enc_out_dim, D});
-    encw_.p2b = wptr(a + "proj2.bias", {cfg_.enc_out_dim});
+    encw_.p2b = fvec(a + "proj2.bias", cfg_.enc_out_dim);
     encw_.layers.clear();
     for (int i = 0; i < cfg_.enc_layers; ++i) {
         const std::string p = a + "layers." + std::to_string(i) + ".";
         EncLayerW L;
-        L.ln1_g = wptr(p + "self_attn_layer_norm.weight", {D});
-        L.ln1_b = wptr(p + "self_attn_layer_norm.bias", {D});
+        L.ln1_g = fvec(p + "self_attn_layer_norm.weight", D);
+        L.ln1_b = fvec(p + "self_attn_layer_norm.bias", D);
         auto wq = std::make_unique<DevBuf>();
         auto bq = std::make_unique<DevBuf>();
         wq->alloc((size_t)3 * D * D * sizeof(bf16_t));
-        bq->alloc((size_t)3 * D * sizeof(bf16_t));
+        bq->alloc((size_t)3 * D * sizeof(float));
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
         for (int j = 0; j < 3; ++j) {
             const bf16_t* w = wptr(p + "self_attn." + names[j] + ".weight", {D, D});
-            const bf16_t* b = wptr(p + "self_attn." + names[j] + ".bias", {D});
+            const float* b = fvec(p + "self_attn." + names[j] + ".bias", D);
             QASR_HIP(hipMemcpyAsync(wq->as<bf16_t>() + (size_t)j * D * D, w, (size_t)D * D * sizeof(bf16_t),
                                     hipMemcpyDeviceToDevice, stream_));
-            QASR_HIP(hipMemcpyAsync(bq->as<bf16_t>() + (size_t)j * D, b, (size_t)D * sizeof(bf16_t),
+            QASR_HIP(hipMemcpyAsync(bq->as<float>() + (size_t)j * D, b, (size_t)D * sizeof(float),
                                     hipMemcpyDeviceToDevice, stream_));
         }
         L.wqkv = wq->as<bf16_t>();
-        L.bqkv = bq->as<bf16_t>();
+        L.bqkv = bq->as<float>();
         fused_.push_back(std::move(wq));
         fused_.push_back(std::move(bq));
         L.wo = wptr(p + "self_attn.out_proj.weight", {D, D});
-        L.bo = wptr(p + "self_attn.out_proj.bias", {D});
-        L.ln2_g = wptr(p + "final_layer_norm.weight", {D});
-        L.ln2_b = wptr(p + "final_layer_norm.bias", {D});
+        L.bo = fvec(p + "self_attn.out_proj.bias", D);
+        L.ln2_g = fvec(p + "final_layer_norm.weight", D);
+        L.ln2_b = fvec(p + "final_layer_norm.bias", D);
         L.w1 = wptr(p + "fc1.weight", {F, D});
-        L.b1 = wptr(p + "fc1.bias", {F});
+        L.b1 = fvec(p + "fc1.bias", F);
         L.w2 = wptr(p + "fc2.weight", {D, F});
-        L.b2 = wptr(p + "fc2.bias", {D});
+        L.b2 = fvec(p + "fc2.bias", D);
         encw_.layers.push_back(L);
     }
     // sinusoid table (AudioEncoder.swift:171-199), float32 arithmetic
@@ -232,18 +251,18 @@ void Engine::run_encoder() {
     }
     const int hd = D / cfg_.enc_heads;
     for (const EncLayerW& L : encw_.layers) {
-        layernorm_launch(x, L.ln1_g, L.ln1_b, h, n_tok_, D, cfg_.ln_eps, s);
-        gemm_nt(ADense{h, D, n_tok_, D}, L.wqkv, D, n_tok_, 3 * D, D, EpiBiasActBf16<0>{qkv, 3L * D, L.bqkv}, s);
+        layernorm_f32p_launch(x, L.ln1_g, L.ln1_b, h, n_tok_, D, cfg_.ln_eps, 0, s);
+        gemm_nt(ADense{h, D, n_tok_, D}, L.wqkv, D, n_tok_, 3 * D, D, EpiBiasActBf16F<0>{qkv, 3L * D, L.bqkv}, s);
         window_attention_launch(qkv, d_cu_win_, n_win_, cfg_.enc_heads, hd, at, s);
-        gemm_nt(ADense{at, D, n_tok_, D}, L.wo, D, n_tok_, D, D, EpiResidF32{x, D, L.bo}, s);
-        layernorm_launch(x, L.ln2_g, L.ln2_b, h, n_tok_, D, cfg_.ln_eps, s);
-        gemm_nt(ADense{h, D, n_tok_, D}, L.w1, D, n_tok_, F, D, EpiBiasActBf16<1>{mid, F, L.b1}, s);
-        gemm_nt(ADense{mid, F, n_tok_, F}, L.w2, F, n_tok_, D, F, EpiResidF32{x, D, L.b2}, s);
+        gemm_nt(ADense{at, D, n_tok_, D}, L.wo, D, n_tok_, D, D, EpiResidF32F{x, D, L.bo}, s);
+        layernorm_f32p_launch(x, L.ln2_g, L.ln2_b, h, n_tok_, D, cfg_.ln_eps, 0, s);
+        gemm_nt(ADense{h, D, n_tok_, D}, L.w1, D, n_tok_, F, D, EpiBiasActBf16F<1>{mid, F, L.b1}, s);
+        gemm_nt(ADense{mid, F, n_tok_, F}, L.w2, F, n_tok_, D, F, EpiResidF32F{x, D, L.b2}, s);
     }
-    layernorm_launch(x, encw_.lnp_g, encw_.lnp_b, h, n_tok_, D, cfg_.ln_eps, s);
-    gemm_nt(ADense{h, D, n_tok_, D}, encw_.p1w, D, n_tok_, D, D, EpiBiasActBf16<1>{at, D, encw_.p1b}, s);
+    layernorm_f32p_launch(x, encw_.lnp_g, encw_.lnp_b, h, n_tok_, D, cfg_.ln_eps, 0, s);
+    gemm_nt(ADense{h, D, n_tok_, D}, encw_.p1w, D, n_tok_, D, D, EpiBiasActBf16F<1>{at, D, encw_.p1b}, s);
     gemm_nt(ADense{at, D, n_tok_, D}, encw_.p2w, D, n_tok_, cfg_.enc_out_dim, D,
-            EpiBiasActBf16<0>{d_audio_.as<bf16_t>(), cfg_.enc_out_dim, encw_.p2b}, s);
+            EpiBiasActBf16F<0>{d_audio_.as<bf16_t>(), cfg_.enc_out_dim, encw_.p2b}, s);
     QASR_HIP(hipGetLastError());
 }
 

@@ -139,6 +139,9 @@ private:
     void run_mel();
     const Tensor& tensor(const std::string& name) const;
     const bf16_t* wptr(const std::string& name, std::initializer_list<int64_t> shape) const;
+    // f32 view of an audio-encoder vector (bias, LayerNorm gain / shift): the reference runs the encoder in f32 with these
+    // tensors widened from the checkpoint dtype, so f16 / f32 checkpoints keep every bit and bf16 ones widen exactly
+    const float* fvec(const std::string& name, int64_t n);
     void finalize_encoder();
     void alloc_encoder_workspace();
     void plan_encoder();          // chunk / token / window tables of the current batch -> HBM
@@ -182,10 +185,12 @@ private:
 
     // ---- audio encoder ---------------------------------------------------------------------
     struct EncLayerW {
-        const bf16_t *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+        const bf16_t *wqkv, *wo, *w1, *w2;                       // MFMA operands: bf16
+        const float *ln1_g, *ln1_b, *bqkv, *bo, *ln2_g, *ln2_b, *b1, *b2;   // biases / LayerNorm parameters: f32 (see fvec)
     };
     struct EncW {
-        const bf16_t *c1w, *c1b, *c2w, *c2b, *c3w, *c3b, *conv_out, *lnp_g, *lnp_b, *p1w, *p1b, *p2w, *p2b;
+        const bf16_t *c1w, *c2w, *c3w, *conv_out, *p1w, *p2w;
+        const float *c1b, *c2b, *c3b, *lnp_g, *lnp_b, *p1b, *p2b;
         std::vector<EncLayerW> layers;
     } encw_;
     std::vector<std::unique_ptr<DevBuf>> fused_;   // concatenated / permuted copies built by finalize

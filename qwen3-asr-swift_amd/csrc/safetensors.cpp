@@ -1,6 +1,9 @@
 // safetensors.cpp -- checkpoint directory loader (HF safetensors shards, reference key names).
 // Reference: Sources/Qwen3ASR/WeightLoading.swift:17-126,235-323, Sources/MLXCommon/WeightLoading.swift:48-165.
-//   audio_tower.*  float tensors (f32 / f16 / bf16 on disk)  -> bf16 in HBM
+//   audio_tower.*  matrices (conv / linear weights; f32 / f16 / bf16 on disk) -> bf16 in HBM: they are MFMA operands, the one
+//                  place an f16 / f32 checkpoint loses bits (the stated bf16-operand deviation);
+//                  vectors (biases, LayerNorm gain / shift) -> f32, exact for every checkpoint dtype: the reference runs
+//                  the encoder in f32 on the widened tensors (tests/test_oracle_loader_precision.py prices both)
 //   model.*        either float Linear weights (FloatTextDecoder) or MLX affine-quantised triplets
 //                  {weight: uint32 [out, in*bits/32], scales, biases: [out, in/group]}, uploaded AS THEY ARE: the packed
 //                  words stay packed in HBM (csrc/dec_quant.h); scales / biases keep bf16, f16 / f32 ones are widened to
@@ -127,6 +130,12 @@ void Engine::load_directory(const std::string& dir) {
         size_t el = e.dtype == "F32" ? 4 : 2;
         if (numel * el != e.bytes) throw std::runtime_error("tensor " + name + ": byte size does not match shape");
         if (e.dtype == "BF16") { set_tensor(name, e.data, QASR_DTYPE_BF16, e.shape.data(), (int)e.shape.size()); return; }
+        if (e.shape.size() == 1 && name.compare(0, 12, "audio_tower.") == 0) {     // encoder vector: keep every bit
+            std::vector<float> wide(numel);
+            for (size_t i = 0; i < numel; ++i) wide[i] = elem_f32(e, i);
+            set_tensor(name, wide.data(), QASR_DTYPE_F32, e.shape.data(), 1);
+            return;
+        }
         tmp.resize(numel);
         for (size_t i = 0; i < numel; ++i) tmp[i] = f32_to_bf16_host(elem_f32(e, i));
         set_tensor(name, tmp.data(), QASR_DTYPE_BF16, e.shape.data(), (int)e.shape.size());

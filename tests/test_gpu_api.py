@@ -182,7 +182,8 @@ def test_safetensors_and_mlx_quantised_checkpoint(tmp_path, sd, bits, sb_dtype):
     """A sharded safetensors directory in the reference's layout (WeightLoading.swift:235-323): MLX-quantised triplets for
     every decoder Linear and the tied embedding, mixed on-disk float dtypes for the audio tower.  The loader must hand the
     engine exactly the tensors `qasr_set_tensor` would: same tokens as an engine built from the same triplets in memory
-    (packed words untouched, bf16 scales kept, f16 scales widened to f32 -- nothing rounded).  Parity of the quantised
+    (packed words untouched, bf16 scales kept, f16 scales widened to f32, f16 / f32 encoder vectors widened to f32 --
+    nothing rounded except f16 / f32 MATRICES of the audio tower, which become bf16 MFMA operands).  Parity of the quantised
     kernels themselves against the oracle: tests/test_gpu_quant.py."""
     from safetensors.torch import save_file
     qsd = synth.quantize_state_dict(sd, bits)
@@ -193,7 +194,10 @@ def test_safetensors_and_mlx_quantised_checkpoint(tmp_path, sd, bits, sb_dtype):
             expect[name] = t if sb_dtype == torch.bfloat16 else t.to(sb_dtype).to(torch.float32)
         elif name.startswith("audio_tower.") and name.endswith(".bias"):
             tensors[name] = t.to(torch.float16)            # mixed on-disk float dtypes
-            expect[name] = t.to(torch.float16).to(torch.bfloat16)
+            expect[name] = t.to(torch.float16).to(torch.float32)   # encoder vectors: widened to f32, no bit lost
+        elif name.startswith("audio_tower.") and name.endswith("layer_norm.weight"):
+            tensors[name] = t.to(torch.float32) * 1.0009765625      # off the bf16 grid: must arrive as it is on disk
+            expect[name] = tensors[name]
         elif name.endswith("layer_norm.weight"):
             tensors[name] = t.to(torch.float32)
             expect[name] = t

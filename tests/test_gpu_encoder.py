@@ -116,3 +116,35 @@ def test_encoder_flip_fraction_grows_like_a_reordered_cpu_sum(depth):
         assert rel_gpu <= 2.0 * rel_cpu + 1e-3, (depth, rel_cpu, rel_gpu)
     finally:
         eng.close()
+
+
+def test_f32_vectors_are_not_rounded_at_load():
+    """An f16 / f32 checkpoint's encoder biases and LayerNorm parameters stay f32 on the device (the reference runs its
+    encoder in f32 on the widened tensors): with vectors that are NOT bf16-representable the device must follow the oracle
+    that uses them as given, and sit measurably closer to it than to the oracle fed their bf16 roundings.  Matrices are
+    bf16 here and there (MFMA operands; tests/test_oracle_loader_precision.py prices both roundings on the CPU)."""
+    cfg = C.AUDIO_TINY
+    sd = synth.synth_state_dict(cfg, C.TEXT_TINY, seed=9, init="stress", dtype=torch.float32)
+    g = torch.Generator().manual_seed(1)
+    exact, rounded = {}, {}
+    for k, v in sd.items():
+        if k.startswith("audio_tower.") and v.dim() == 1:
+            v = (v + 0.37 * (v.abs() + 0.05) * torch.rand(v.shape, generator=g) * 2.0 ** -7).to(torch.float32)   # off the bf16 grid
+            exact[k], rounded[k] = v, v.to(torch.bfloat16).to(torch.float32)
+        else:
+            exact[k] = rounded[k] = v.to(torch.bfloat16)
+    e = gpu_util.Engine("tiny", max_audio_seconds=30)
+    try:
+        e.load_state_dict(exact)
+        mel = (torch.randn(128, 300, generator=g) * 0.5).numpy()
+        got = e.encode(mel)
+        with torch.no_grad():
+            want = encoder.encode(mel, decoder.Weights(exact), cfg, P.DEVICE).numpy()
+            other = encoder.encode(mel, decoder.Weights(rounded), cfg, P.DEVICE).numpy()
+        r_exact = np.linalg.norm(got - want) / np.linalg.norm(want)
+        r_round = np.linalg.norm(got - other) / np.linalg.norm(other)
+        r_gap = np.linalg.norm(want - other) / np.linalg.norm(want)
+        print(f"device vs oracle(f32 vectors) {r_exact:.2e}; vs oracle(bf16-rounded vectors) {r_round:.2e}; oracle gap {r_gap:.2e}")
+        assert r_exact < 1e-2 and r_exact < r_round
+    finally:
+        e.close()
