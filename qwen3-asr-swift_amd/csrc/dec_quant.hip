@@ -1,6 +1,8 @@
 // dec_quant.hip -- decode-step kernels on MLX affine-quantised weights (see dec_quant.h).
 #include "dec_quant.h"
 #include "dec_epilogue.h"
+#include "gemm.h"      // lds_ptr_t / glb_ptr_t
+#include "tuning.h"
 #include <cstdio>
 
 namespace qasr {
@@ -489,6 +491,7 @@ void decode_gemv_q_launch(DecEpi epi, const DecGemvArgs& a, const QuantImg& w, c
 // (166 / 224 at 16 / 32 rows), so the kernel runs one workgroup per CU at two waves per SIMD.
 // ------------------------------------------------------------------------------------------------
 constexpr int LMQ_WAVES = 8;
+typedef __attribute__((ext_vector_type(4))) unsigned lds_u32x4;
 
 struct LmHeadQArgs {
     const uint32_t* qp;
@@ -502,16 +505,30 @@ struct LmHeadQArgs {
     int* part_idx;
 };
 
-template <int BITS, bool SBF32, int K, int NB>
-__global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char dsm[];
+// LR > 0: the weight stream goes through a wave-private LDS ring of LR one-KiB slots instead (direct-to-LDS loads, each lane
+// reads back the 16 bytes it requested): LDS as an extension of the register file for bytes in flight.  Per 16-row tile the
+// wave's block sequence is [scale / bias block(s), q block 0 .. NBLK-1]; block c is consumed after `s_waitcnt vmcnt(LR - 1)`
+// (LR blocks are always outstanding: block c + LR is requested as soon as block c has been read, dummy blocks past the end),
+// scale / bias blocks are copied to a per-wave "current tile" area so that their slot is free at once.  8 waves x LR KiB in
+// flight per CU instead of 32 KiB.
+template <int BITS, bool SBF32, int K, int NB, int LR>
+__global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a, const char* __restrict__ qsrc,
+                                                                   const char* __restrict__ sbsrc) {
     constexpr int BLK = BITS == 4 ? 128 : 64, GPB = BLK / 64, NBLK = K / BLK, G = K / 64;
     constexpr int KCH = K / 8, XSTRIDE = 2 * K + 16, TPR = 32, XI = KCH / TPR;
     constexpr int RING = 4;                                       // 16-byte q blocks in flight per lane
     static_assert(NBLK % RING == 0, "K must be a multiple of 512");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    constexpr int SBB = 2 * 16 * G * (SBF32 ? 4 : 2) / 1024;      // scale / bias KiB per tile
+    constexpr int PT = SBB + NBLK;                                // blocks per tile in the LDS-ring form
+    constexpr size_t XBYTES = ((size_t)NB * 16 * XSTRIDE + (size_t)G * NB * 16 * 4 + 1023) / 1024 * 1024;
+    // ONE statically sized LDS object: with a dynamic array hipcc cannot tell the ring from the activation image and drains
+    // vmcnt to 0 in front of every LDS read while a direct-to-LDS load is in flight
+    __shared__ __attribute__((aligned(1024))) char dsm[XBYTES + (LR > 0 ? (size_t)LMQ_WAVES * (LR + SBB) * 1024 : 0)];
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fc = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* s_x = dsm;                                                            // [NB*16][XSTRIDE]
     float* s_xs = reinterpret_cast<float*>(dsm + (size_t)NB * 16 * XSTRIDE);     // [G][NB*16]
+    char* ring = dsm + XBYTES + (size_t)wave * (LR + SBB) * 1024;                // LR slots, then the current tile's scale / bias image
     const int total_waves = gridDim.x * LMQ_WAVES, gw = blockIdx.x * LMQ_WAVES + wave;
     const int ntiles = a.N / 16;
     const int my_tiles = gw < ntiles ? (ntiles - gw + total_waves - 1) / total_waves : 0;
@@ -531,7 +548,21 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
             bi[h] = eff_bias<BITS>(sc[h], sb_at<SBF32>(a.sb, ((tile * 2 + 1) * 16 + fr) * G + kb * GPB + h));
         }
     };
-    if (nblocks > 0) {
+    // LDS-ring form: request block `seq` of this wave's sequence into slot seq % LR (a dummy block past the end)
+    const int nseq = my_tiles * PT;
+    auto issue = [&](int seq) {
+        const char* src = qsrc;
+        if (seq < nseq) {
+            const int ti = seq / PT, j = seq - ti * PT;
+            const long tile = gw + (long)ti * total_waves;
+            src = j < SBB ? sbsrc + (tile * SBB + j) * 1024 : qsrc + (tile * NBLK + (j - SBB)) * 1024;
+        }
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + lane * 16), (lds_ptr_t)(ring + (seq % (LR > 0 ? LR : 1)) * 1024), 16, 0, 0);
+    };
+    if constexpr (LR > 0) {
+#pragma unroll 1
+        for (int r = 0; r < LR; ++r) issue(r);
+    } else if (nblocks > 0) {
 #pragma unroll
         for (int r = 0; r < RING; ++r) load_blk(qr[r], scr[r], bir[r], r);
     }
@@ -588,6 +619,71 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
 #pragma unroll
         for (int j = 0; j < 4; ++j) { best[b][j] = -INFINITY; bidx[b][j] = 0x7fffffff; }
     }
+    if constexpr (LR > 0) {
+        const char* sbcur = ring + LR * 1024;
+#pragma unroll 1
+        for (int ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll 1
+            for (int j = 0; j < PT; ++j) {
+                const int seq = ti * PT + j;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LR - 1) : "memory");       // block seq has landed
+                // native vector type on purpose: hipcc's wait insertion leaves an LDS read alone while direct-to-LDS loads are in
+                // flight only if the read carries type-based alias info (a HIP_vector_type / char access gets `vmcnt(0)` in
+                // front of it, which would serialise the ring); the counted wait above is the real dependency
+                const lds_u32x4 raw = *reinterpret_cast<const lds_u32x4*>(ring + (seq % LR) * 1024 + lane * 16);
+                const uint4 blk = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+                if (j < SBB) {                                  // wave-uniform
+                    *reinterpret_cast<lds_u32x4*>(const_cast<char*>(sbcur) + j * 1024 + lane * 16) = raw;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the slot has been read before it is requested again
+                    issue(seq + LR);
+                    continue;
+                }
+                const int kb = j - SBB;
+                mfma_bf16x8 wf[2 * GPB];
+#pragma unroll
+                for (int h = 0; h < GPB; ++h) {
+                    wf[2 * h] = frag_of<BITS>(blk, 2 * h + 0);
+                    wf[2 * h + 1] = frag_of<BITS>(blk, 2 * h + 1);
+                }
+                float sg[GPB], bg[GPB];
+#pragma unroll
+                for (int h = 0; h < GPB; ++h) {
+                    sg[h] = sb_at<SBF32>(sbcur, (0 * 16 + fr) * G + kb * GPB + h);
+                    bg[h] = eff_bias<BITS>(sg[h], sb_at<SBF32>(sbcur, (1 * 16 + fr) * G + kb * GPB + h));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                issue(seq + LR);                                // blk is in registers (the fragment conversion consumed it)
+                const char* xw = s_x + (size_t)fr * XSTRIDE + fc * 16 + (size_t)kb * GPB * 128;
+                const float* xsw = s_xs + (size_t)kb * GPB * (NB * 16) + fc * 4;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                    for (int h = 0; h < GPB; ++h) {
+                        const mfma_bf16x8 x0 = *reinterpret_cast<const mfma_bf16x8*>(xw + (size_t)b * 16 * XSTRIDE + (h * 2 + 0) * 64);
+                        const mfma_bf16x8 x1 = *reinterpret_cast<const mfma_bf16x8*>(xw + (size_t)b * 16 * XSTRIDE + (h * 2 + 1) * 64);
+                        const f32x4 xs = *reinterpret_cast<const f32x4*>(xsw + h * (NB * 16) + b * 16);
+                        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, wf[2 * h], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, wf[2 * h + 1], acc, 0, 0, 0);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) tot[b][jj] += sg[h] * acc[jj] + bg[h] * xs[jj];
+                    }
+                }
+            }
+            const int n = (gw + ti * total_waves) * 16 + fr;    // tile complete: tot[b][j] = logit[batch b*16 + fc*4 + j][n]
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = b * 16 + fc * 4 + jj;
+                    const float v = bf16_round(tot[b][jj]);
+                    if (a.logits && row < a.B) a.logits[(long)row * a.N + n] = v;
+                    if (v > best[b][jj] || (v == best[b][jj] && n < bidx[b][jj])) { best[b][jj] = v; bidx[b][jj] = n; }
+                    tot[b][jj] = 0.0f;
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dummy blocks still in flight write LDS
+    } else {
 #pragma unroll 1
     for (int b0 = 0; b0 < nblocks; b0 += RING) {
 #pragma unroll
@@ -636,6 +732,7 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
                 }
         }
     }
+    }
     // ---- argmax partial of the workgroup: over the 16 weight rows of a lane group, then over the waves ----------
     float* s_v = reinterpret_cast<float*>(dsm);                                   // the activation image is dead now
     int* s_i = reinterpret_cast<int*>(dsm + LMQ_WAVES * NB * 16 * sizeof(float));
@@ -678,16 +775,28 @@ static bool lm_head_q_supported(int N, int K, int bits) {
 }
 int lm_head_q_parts(int N, int K, int bits) { return lm_head_q_supported(N, K, bits) ? LMQ_GRID : 1; }
 
+template <int BITS, bool SBF32, int K, int NB, int LR>
+static void lm_head_q_go1(const LmHeadQArgs& a, hipStream_t s) {
+    constexpr size_t xbytes = ((size_t)NB * 16 * (2 * K + 16) + (size_t)(K / 64) * NB * 16 * 4 + 1023) / 1024 * 1024;
+    constexpr int sbb = 2 * 16 * (K / 64) * (SBF32 ? 4 : 2) / 1024;
+    constexpr size_t lds = xbytes + (LR > 0 ? (size_t)LMQ_WAVES * (LR + sbb) * 1024 : 0);
+    static_assert(lds <= 160 * 1024, "LM head: LDS image + weight ring exceed the CU");
+    auto kern = lm_head_q_kernel<BITS, SBF32, K, NB, LR>;
+    hipLaunchKernelGGL(kern, dim3(LMQ_GRID), dim3(LMQ_WAVES * 64), 0, s, a, reinterpret_cast<const char*>(a.qp),
+                       reinterpret_cast<const char*>(a.sb));
+}
+
+// ring depth by what the activation image leaves of the 160 KiB (K = 1024: 33 KiB per batch tile): 13 slots per wave at
+// <= 16 rows, 9 at <= 32 (f32 scales: one slot less); larger batches / hidden sizes keep the register ring
 template <int BITS, bool SBF32, int K, int NB>
 static void lm_head_q_go(const LmHeadQArgs& a, hipStream_t s) {
-    constexpr size_t lds = (size_t)NB * 16 * (2 * K + 16) + (size_t)(K / 64) * NB * 16 * 4;
-    auto kern = lm_head_q_kernel<BITS, SBF32, K, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    if constexpr (K == 1024 && NB <= 2) {
+        if (tuning().lmh_q_ring != 0) {
+            lm_head_q_go1<BITS, SBF32, K, NB, (NB == 1 ? 13 : 9) - (SBF32 ? 1 : 0)>(a, s);
+            return;
+        }
     }
-    hipLaunchKernelGGL(kern, dim3(LMQ_GRID), dim3(LMQ_WAVES * 64), lds, s, a);
+    lm_head_q_go1<BITS, SBF32, K, NB, 0>(a, s);
 }
 
 template <int BITS, bool SBF32, int K>

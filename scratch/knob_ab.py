@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--tokens", type=int, default=128)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--bits", type=int, default=16, choices=[16, 8, 4], help="16 = bf16 decoder, 4 / 8 = MLX-quantised, packed")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     variants = []
@@ -35,7 +36,9 @@ def main():
             knobs[k] = int(val)
         variants.append((name, knobs))
     sd = synth.synth_state_dict(QC.AUDIO_SMALL, QC.TEXT_SMALL, seed=0, init="hf")
-    m = Qwen3ASRModel.from_state_dict(sd, preset="0.6B", max_batch=a.batch, max_audio_seconds=int(np.ceil(a.seconds)),
+    if a.bits != 16:
+        sd = synth.quantize_state_dict(sd, a.bits)
+    m = Qwen3ASRModel.from_state_dict(sd, preset="0.6B", bits=a.bits, max_batch=a.batch, max_audio_seconds=int(np.ceil(a.seconds)),
                                       max_new_tokens=448)
     clips = [synth.synth_waveform(k, a.seconds) for k in range(a.batch)]
     m.batch_begin(clips, max_tokens=a.tokens, ignore_eos=True)

@@ -106,6 +106,33 @@ def test_full_width_tuned_kernels(full_sd, bits, sb_f32):
         eng.close()
 
 
+@pytest.mark.parametrize("bits,sb_f32", [(4, False), (8, True)], ids=["w4", "w8-f32scales"])
+def test_lm_head_weight_rings_agree_bit_for_bit(full_sd, bits, sb_f32):
+    """The quantised LM head streams its weights either through a four-block register ring or through a wave-private LDS
+    ring fed by direct-to-LDS loads (9-13 KiB in flight per wave); both consume the blocks in the same order with the same
+    arithmetic: same logits bits at 1 row, same tokens at 32 rows (two batch tiles, shallower ring)."""
+    qsd = synth.quantize_state_dict(full_sd, bits)
+    if sb_f32:
+        qsd = {k: (v.to(torch.float32) if k.endswith((".scales", ".biases")) else v) for k, v in qsd.items()}
+    eng = gpu_util.Engine("0.6B", max_batch=32, max_audio_seconds=6, max_new_tokens=16, dec_layers=3, bits=bits)
+    try:
+        eng.load_state_dict(qsd)
+        emb = P.bf16_round(torch.randn(33, 1024, generator=torch.Generator().manual_seed(4)) * 0.5).numpy()
+        clips = [synth.synth_waveform(k, 1.0 + 0.13 * (k % 4)) for k in range(32)]
+        res = []
+        for ring in (0, 1):
+            eng.set_tuning("lmh_q_ring", ring)
+            first = eng.prefill_logits(emb)
+            steps = eng.decode_forced([int(first.argmax()), 17, 151643, 5])
+            res.append((first, steps, eng.transcribe_batch(clips, max_tokens=6, ignore_eos=True)))
+        assert np.array_equal(res[0][0], res[1][0])
+        assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+        assert res[0][2] == res[1][2]
+    finally:
+        eng.set_tuning("lmh_q_ring", 1)
+        eng.close()
+
+
 def test_quantised_differs_from_its_bf16_expansion(full_sd):
     """Why the packed kernels exist: a decode step on bf16(scale * q + bias) weights (what round 1 did at load) is NOT
     what the reference computes.  On the same 4-bit triplets the two give measurably different logits; the device
