@@ -1,4 +1,5 @@
 // ctc_engine.hip -- Omnilingual ASR engine (see ctc_engine.h).
+#include <thread>
 #include "ctc_engine.h"
 #include "safetensors.h"
 #include <algorithm>
@@ -55,7 +56,7 @@ CtcEngine::CtcEngine(const qasr_ctc_config& cfg) : cfg_(cfg) {
     d_att_.alloc((size_t)cap_frames_ * D * sizeof(bf16_t));
     d_mid_.alloc((size_t)cap_frames_ * cfg_.ffn_dim * sizeof(bf16_t));
     d_logits_.alloc((size_t)cap_frames_ * cfg_.vocab * sizeof(float));
-    d_ids_.alloc((size_t)cap_frames_ * sizeof(int));
+    d_ids_.alloc(((size_t)cap_frames_ + 1) * sizeof(int));   // + the non-finite flag
     d_info_.alloc((size_t)cap_frames_ * sizeof(int2));
 }
 
@@ -298,10 +299,22 @@ void CtcEngine::forward(const float* const* pcm, const size_t* n, size_t Bz, std
         if ((long)n[b] > max_samples_) throw std::length_error("clip longer than max_audio_seconds");
         h_off[b] = off;
         h_ns[b] = (int)n[b];
-        std::memcpy(h_pcm_.as<float>() + off, pcm[b], n[b] * sizeof(float));
         off += ((long)n[b] + 1) & ~1L;
         long L = (long)n[b];
         for (int i = 0; i < 7; ++i) { L = conv_len(L, i); lv_n(i)[b] = (int)L; }
+    }
+    // caller memory (pageable) -> pinned staging on a few threads, whole clips each (61 MB at 32 x 30 s)
+    {
+        const int nthr = off > (1L << 20) ? std::min(B, 8) : 1;
+        auto copy_range = [&](int b0, int b1) {
+            for (int b = b0; b < b1; ++b) std::memcpy(h_pcm_.as<float>() + h_off[b], pcm[b], n[b] * sizeof(float));
+        };
+        if (nthr <= 1) copy_range(0, B);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; ++t) pool.emplace_back(copy_range, B * t / nthr, B * (t + 1) / nthr);
+            for (auto& th : pool) th.join();
+        }
     }
     int max_n0 = 0, max_frames = 0;
     for (int i = 0; i < 7; ++i) {
@@ -365,19 +378,24 @@ void CtcEngine::forward(const float* const* pcm, const size_t* n, size_t Bz, std
         // ---- final LayerNorm, CTC head, per-frame argmax -------------------------------------------------------------
         layernorm_f32p_launch(x, final_g_, final_b_, h, Ftot, D, cfg_.ln_eps, 0, s);
         gemm_nt(ADense{h, D, Ftot, D}, head_.w, D, Ftot, V, D, EpiBiasF32{d_logits_.as<float>(), V, head_.b}, s);
-        argmax_f32_launch(d_logits_.as<float>(), V, Ftot, V, d_ids_.as<int>(), s);
+        int* d_err = d_ids_.as<int>() + cap_frames_;
+        QASR_HIP(hipMemsetAsync(d_err, 0, sizeof(int), s));
+        argmax_f32_launch(d_logits_.as<float>(), V, Ftot, V, d_ids_.as<int>(), d_err, s);
     } else {
         QASR_HIP(hipEventRecord(ev_[1], s));
         QASR_HIP(hipEventRecord(ev_[2], s));
     }
     QASR_HIP(hipEventRecord(ev_[3], s));
     std::vector<int> ids((size_t)std::max(Ftot, 1));
+    int bad = 0;
     if (Ftot > 0) {
         QASR_HIP(hipMemcpyAsync(ids.data(), d_ids_.p, (size_t)Ftot * sizeof(int), hipMemcpyDeviceToHost, s));
+        QASR_HIP(hipMemcpyAsync(&bad, d_ids_.as<int>() + cap_frames_, sizeof(int), hipMemcpyDeviceToHost, s));
         if (logits) QASR_HIP(hipMemcpyAsync(logits, d_logits_.p, (size_t)Ftot * V * sizeof(float), hipMemcpyDeviceToHost, s));
     }
     QASR_HIP(hipStreamSynchronize(s));
     QASR_HIP(hipGetLastError());
+    if (bad) throw HipError("omnilingual: non-finite logits (corrupt weights or input)");
     for (int b = 0; b < B; ++b) frame_ids[b].assign(ids.begin() + lv_off(6)[b], ids.begin() + lv_off(6)[b] + lv_n(6)[b]);
 }
 

@@ -123,7 +123,9 @@ struct EpiPosConv {
 void mha_attention_launch(const bf16_t* qkv, const int* cu, int n_clips, int max_len, int heads, int head_dim, bf16_t* out,
                           hipStream_t s);
 
-// ids[r] = first index of the maximum of x[r][0 .. n)   (CTCGreedyDecoder.swift:39-48: strict '>' keeps the first maximum)
-void argmax_f32_launch(const float* x, long ld, int rows, int n, int* ids, hipStream_t s);
+// ids[r] = first index of the maximum of x[r][0 .. n)   (CTCGreedyDecoder.swift:39-48: strict '>' keeps the first maximum).
+// *err |= 1 if any logit is NaN / infinite (the reference would silently emit whatever its comparisons leave; the engine
+// turns this into an error status, like the Qwen3 path's non-finite check).
+void argmax_f32_launch(const float* x, long ld, int rows, int n, int* ids, int* err, hipStream_t s);
 
 }  // namespace qasr

@@ -259,16 +259,20 @@ void cast_f32_bf16_launch(const float* x, bf16_t* y, long n, hipStream_t s) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, x, y, n / 4);
 }
 
-__global__ __launch_bounds__(256) void argmax_f32_kernel(const float* __restrict__ x, long ld, int n, int* __restrict__ ids) {
+__global__ __launch_bounds__(256) void argmax_f32_kernel(const float* __restrict__ x, long ld, int n, int* __restrict__ ids,
+                                                         int* __restrict__ err) {
     __shared__ float s_v[256];
     __shared__ int s_i[256];
     const float* row = x + (long)blockIdx.x * ld;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
+    bool bad = false;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float v = row[i];
+        bad |= !(fabsf(v) <= 3.0e38f);                     // NaN or infinity: a broken checkpoint, not a transcript
         if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
     }
+    if (bad && err) atomicOr(err, 1);
     s_v[threadIdx.x] = bv;
     s_i[threadIdx.x] = bi;
     __syncthreads();
@@ -283,9 +287,9 @@ __global__ __launch_bounds__(256) void argmax_f32_kernel(const float* __restrict
     if (threadIdx.x == 0) ids[blockIdx.x] = s_i[0] == 0x7fffffff ? 0 : s_i[0];      // all-NaN row: index 0, like the reference's loop
 }
 
-void argmax_f32_launch(const float* x, long ld, int rows, int n, int* ids, hipStream_t s) {
+void argmax_f32_launch(const float* x, long ld, int rows, int n, int* ids, int* err, hipStream_t s) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(argmax_f32_kernel, dim3(rows), dim3(256), 0, s, x, ld, n, ids);
+    hipLaunchKernelGGL(argmax_f32_kernel, dim3(rows), dim3(256), 0, s, x, ld, n, ids, err);
 }
 
 }  // namespace qasr

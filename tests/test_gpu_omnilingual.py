@@ -127,6 +127,24 @@ def test_reference_error_behaviour(tiny):
         m2.close()
 
 
+def test_non_finite_logits_are_an_error_status(tiny):
+    """A NaN anywhere in the weights reaches the logits; the engine reports it (QASR_ERR_HIP, 'non-finite') instead of
+    returning whatever token ids the comparisons leave -- same policy as the Qwen3 path's greedy loop."""
+    _, sd = tiny
+    bad = dict(sd)
+    name = "encoder.layers.1.ffn.output_proj.bias"
+    t = bad[name].clone().to(torch.float32)
+    t[3] = float("nan")
+    bad[name] = t
+    m = OmnilingualASRMLXModel.from_state_dict(bad, variant="tiny", max_batch=2, max_audio_seconds=4)
+    try:
+        with pytest.raises(QasrError, match="non-finite"):
+            m.transcribe_audio(_wave(1, 1.5))
+        assert m.transcribe(_wave(1, 1.5)) == ""                  # the never-raising protocol surface
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("bits", [0, 4, 8], ids=["float", "mlx-4bit", "mlx-8bit"])
 def test_300m_width_two_layers(bits):
     """Omnilingual-300M widths (D 1024, 16 heads x 64, FFN 4096, 512-channel extractor, k = 128 / 16-group positional conv,
