@@ -186,6 +186,14 @@ int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps);
  * and algorithmic bytes per launch.  which: 0 = decode-step weight-streaming GEMV group,
  * 1 = decode attention, 2 = LM head; 3 / 4 = prompt-pass QKV / gate-up GEMM (bytes_per_launch then holds FLOPs). */
 int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch);
+/* Diagnostic: the MFMA GEMM the encoder / prompt pass / wav2vec2 path are built on, by itself.  out[M][N] (f32, host) =
+ * A[M][K] . W[N][K]^T + bias[N] with bf16 operands (host arrays of bf16 bit patterns), f32 accumulation, f32 bias (may be
+ * NULL).  form: 0 = 128x128 double-buffered, 1 = 128x128 single LDS buffer, 2 = 256x256 ping-pong (csrc/gemm_p8.h),
+ * -1 = whatever the engine would pick for this shape.  K % 8 == 0 and N % 4 == 0 like every caller.  Needs no weights;
+ * no reference counterpart (MLX supplies the matmul there) -- used by tests/test_gpu_gemm.py to compare the forms with
+ * each other bit for bit and with a float64 product on ragged shapes.  *avg_ms (may be NULL): mean of `reps` launches. */
+int qasr_gemm_probe(qasr_engine* e, const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int K, int form,
+                    int reps, float* out, float* avg_ms);
 
 /* ---- tuning / diagnostic knobs ----------------------------------------------------------------
  * Process-wide A/B switches between kept kernel variants (csrc/tuning.h lists them with their measurements: "gemm_nbuf",

@@ -176,6 +176,13 @@ int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double
     QASR_GUARD(e, e->impl->kernel_probe(which, reps, avg_ms, bytes_per_launch));
 }
 
+int qasr_gemm_probe(qasr_engine* e, const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int K, int form,
+                    int reps, float* out, float* avg_ms) {
+    if (!e || !A || !W || !out || M <= 0 || N <= 0 || K <= 0 || K % 8 || N % 4 || form < -1 || form > 2 || reps <= 0)
+        return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->gemm_probe(A, W, bias, M, N, K, form, reps, out, avg_ms));
+}
+
 int qasr_transcribe_batch(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B, int sample_rate,
                           const qasr_options* opt, int32_t* tokens, int32_t* lens) {
     if (!e || !tokens || !lens) return QASR_ERR_INVALID;

@@ -101,6 +101,8 @@ public:
     void batch_sync();
     void batch_tokens(int32_t* tokens, int32_t* lens);
     void batch_timings(float ms[5], int32_t* n_steps);
+    void gemm_probe(const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int K, int form, int reps, float* out,
+                    float* avg_ms);
     void kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_launch);
     int batch_size() const { return batch_; }
     void require_asr(const char* what) const {

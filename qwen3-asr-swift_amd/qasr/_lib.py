@@ -98,6 +98,7 @@ SIGNATURES = {
     "qasr_batch_tokens": (C.c_int, [_E, _I, _I]),
     "qasr_batch_timings": (C.c_int, [_E, _F, _I]),
     "qasr_kernel_probe": (C.c_int, [_E, C.c_int, C.c_int, _F, _P(C.c_double)]),
+    "qasr_gemm_probe": (C.c_int, [_E, _P(C.c_uint16), _P(C.c_uint16), _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]),
     "qasr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "qasr_get_tuning": (C.c_int, [C.c_char_p, _P(C.c_int)]),
     "qasr_num_mel_frames": (C.c_int, [C.c_size_t]),

@@ -43,12 +43,13 @@ def gather_tokens(tokens, lens, n_clips, device=None):
     return allr[:, :S].copy(), allr[:, S].copy()
 
 
-def transcribe_sharded(model, clips, device=None, **opt):
-    """Every rank passes the full clip list; returns the full token lists on every rank."""
+def transcribe_sharded(model, clips, device=None, max_len=None, **opt):
+    """Every rank passes the full clip list; returns the full token lists on every rank.  max_len: longest id list a clip can
+    produce (default: the Qwen3 engine's max_new_tokens + 1; the wav2vec2-CTC engine passes its frame capacity)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_bounds(len(clips), world, rank)
-    S = model.cfg.max_new_tokens + 1
+    S = int(max_len) if max_len is not None else model.cfg.max_new_tokens + 1
     toks = np.full((hi - lo, S), -1, dtype=np.int32)
     lens = np.zeros(hi - lo, dtype=np.int32)
     if hi > lo:

@@ -45,8 +45,16 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--ab", default="", help="knob=v1,v2,...: repeat the timed region per value of one tuning knob")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (launch with torch.distributed.run for > 1): --batch clips PER GPU, "
+                                                          "clips sharded, one all_gather of the padded id block per pass")
     a = ap.parse_args()
-    m = OmnilingualASRMLXModel(variant=a.variant, max_batch=a.batch, max_audio_seconds=int(np.ceil(a.seconds)))
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl" if os.environ.get("QASR_DIST_BACKEND", "nccl") == "nccl" else "gloo")
+    m = OmnilingualASRMLXModel(variant=a.variant, device=local if world > 1 else 0, max_batch=a.batch,
+                               max_audio_seconds=int(np.ceil(a.seconds)))
     cfg = m.cfg
     t0 = time.perf_counter()
     sd = synth.synth_omnilingual_state_dict(cfg, seed=0, bits=0)
@@ -58,7 +66,37 @@ def main():
     del sd
     m._check(m.lib.qasr_ctc_finalize(m.h))
     print(f"[bench_ctc] weights built + uploaded in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
-    clips = [synth.synth_waveform(k, a.seconds) for k in range(a.batch)]
+    clips = [synth.synth_waveform(k, a.seconds) for k in range(rank * a.batch, (rank + 1) * a.batch)]   # weak scaling: own clips
+    if world > 1:
+        from qasr import dist as qdist
+        S = m.num_frames(len(clips[0])) + 1
+        dev = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
+        gathered = torch.empty((world * a.batch, S), dtype=torch.int32, device=dev)
+
+        def one_pass():
+            ids = m.transcribe_batch(clips)
+            block = np.full((a.batch, S), -1, np.int32)
+            for i, t in enumerate(ids):
+                block[i, :len(t)] = t
+                block[i, S - 1] = len(t)
+            dist.all_gather_into_tensor(gathered, torch.from_numpy(block).to(dev))
+            return ids
+        one_pass()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            ids = one_pass()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item()) / a.steps
+        if rank == 0:
+            print(json.dumps({"metric": f"audio-seconds/sec Omnilingual-ASR-CTC-{a.variant}, {a.seconds:.0f} s @ 16 kHz, b={a.batch} per GPU",
+                              "value": round(world * a.batch * a.seconds / dt, 1), "n_gpus": world, "ms_per_step": round(dt * 1e3, 2),
+                              "scaling": "weak", "data": "synthetic", "gathered_rows": int((gathered[:, S - 1] >= 0).sum())}), flush=True)
+        m.close()
+        dist.destroy_process_group()
+        return
     if a.ab:
         key, vals = a.ab.split("=")
         for v in vals.split(","):

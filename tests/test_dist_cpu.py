@@ -45,6 +45,41 @@ def _worker(rank, world, port, n_clips, q):
         dist.destroy_process_group()
 
 
+class _FakeCtcModel:
+    """wav2vec2-CTC stand-in: ragged id lists up to the frame capacity (no max_new_tokens in its config)."""
+    max_len = 40
+
+    def transcribe_batch(self, clips, **opt):
+        return [[(int(c[1]) * 7 + i) % 10288 for i in range((int(c[1]) * 13) % (self.max_len + 1))] for c in clips]
+
+
+def _ctc_worker(rank, world, port, n_clips, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        clips = [np.array([0.0, k], dtype=np.float32) for k in range(n_clips)]
+        q.put((rank, qd.transcribe_sharded(_FakeCtcModel(), clips, max_len=_FakeCtcModel.max_len)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ctc_ids_world2():
+    """The Omnilingual path shards like the Qwen3 one (clips independent); its id lists are ragged up to the frame count,
+    including empty ones (a clip that collapses to nothing) and full-capacity ones."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ctc_worker, args=(r, 2, port, 9, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = _FakeCtcModel().transcribe_batch([np.array([0.0, k], dtype=np.float32) for k in range(9)])
+    assert any(len(e) == 0 for e in expect) and any(len(e) == 39 for e in expect)
+    assert results[0] == expect and results[1] == expect
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
