@@ -64,6 +64,20 @@ def test_forms_vs_float64_and_each_other(eng, M, N, K):
     assert np.abs(nobias - (want - bias)).max() <= 2e-6 * mag.max()
 
 
+@pytest.mark.parametrize("M,N,K", [(4097, 3072, 1024), (2049, 1024, 4096), (12992, 6144, 1024)])
+def test_p8_is_repeatable(eng, M, N, K):
+    """Race screen for the ping-pong schedule of gemm_p8.h (LDS units restaged while the other wave group still computes,
+    counted vmcnt across raw barriers): 25 launches of several tiles per workgroup must give the same bits every time and
+    the bits of the single-buffer 128 x 128 form (a race would show as a wrong tile that comes and goes)."""
+    rng = np.random.default_rng(K + N)
+    A16, _ = _bf16(rng.standard_normal((M, K), dtype=np.float32))
+    W16, _ = _bf16(rng.standard_normal((N, K), dtype=np.float32))
+    ref, _ = _run(eng, A16, W16, None, M, N, K, 1)
+    for i in range(25):
+        got, _ = _run(eng, A16, W16, None, M, N, K, 2, reps=2)
+        assert np.array_equal(got, ref), i
+
+
 def test_refused_shapes(eng):
     z = np.zeros((8, 8), np.uint16)
     o = np.zeros((8, 8), np.float32)
@@ -75,7 +89,8 @@ def test_refused_shapes(eng):
 
 def test_throughput_report(eng):
     """not an assertion on speed: prints TFLOP/s of the three forms on two benchmark shapes for the round's notes"""
-    for M, N, K in ((12992, 6144, 1024), (47968, 3072, 1024), (47968, 1024, 4096)):
+    for M, N, K in ((12992, 6144, 1024), (12992, 4096, 1024), (12992, 1024, 2048), (12992, 1024, 3072), (12480, 2688, 896),
+                    (12480, 896, 3584), (12480, 3584, 896), (47968, 3072, 1024), (47968, 1024, 4096)):
         rng = np.random.default_rng(1)
         A16, _ = _bf16(rng.standard_normal((M, K), dtype=np.float32))
         W16, _ = _bf16(rng.standard_normal((N, K), dtype=np.float32))

@@ -127,6 +127,25 @@ def test_reference_error_behaviour(tiny):
         m2.close()
 
 
+def test_maximum_clip_length_40s():
+    """The reference's cap (40 s = 640 000 samples -> 1999 frames, OmnilingualMLXModel.swift:154-159) at the 300M widths, one
+    layer: the longest attention sweep (32 key tiles, 16 query blocks per head), the largest conv row tables, and one sample
+    more is refused."""
+    cfg = dataclasses.replace(O.VARIANTS["300M"], layers=1)
+    sd = synth.synth_omnilingual_state_dict(cfg, seed=13)
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="300M", layers=1, max_batch=2, max_audio_seconds=40)
+    try:
+        pcm = _wave(6, 40.0)
+        assert len(pcm) == 640000 and O.output_length(len(pcm)) == 1999
+        _check_logits(m, sd, cfg, pcm, "40 s clip, 300M width")
+        ids = m.transcribe_batch([pcm, _wave(7, 3.3)])
+        assert ids[0] == m.transcribe_batch([pcm])[0] and len(ids[0]) <= 1999
+        with pytest.raises(QasrError, match="qasr error 5"):
+            m.transcribe_audio(np.concatenate([pcm, np.zeros(1, np.float32)]))
+    finally:
+        m.close()
+
+
 def test_non_finite_logits_are_an_error_status(tiny):
     """A NaN anywhere in the weights reaches the logits; the engine reports it (QASR_ERR_HIP, 'non-finite') instead of
     returning whatever token ids the comparisons leave -- same policy as the Qwen3 path's greedy loop."""
