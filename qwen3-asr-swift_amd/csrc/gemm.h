@@ -2,13 +2,10 @@
 // with pluggable A-operand gathers (dense rows / row-offset table / implicit 3x3-stride-2 conv) and
 // fused epilogues.  gfx950 only: v_mfma_f32_16x16x32_bf16, 64-lane waves, XOR-swizzled LDS tiles.
 //
-// Tile: 128 x 128 x 64 per workgroup of 4 waves (2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles).
-// Staging: global_load_dwordx4 -> registers -> ds_write_b128 into a double-buffered LDS image whose
-// 16-byte chunk index is XORed with (row & 7): the MFMA fragment reads (ds_read_b128, 16 rows x one
-// chunk column per 16 lanes) and the staging writes (8 lanes = one 128-byte row) are both
-// bank-conflict free.  Loads for tile k+1 are issued before the MFMAs of tile k and written to LDS
-// after them (one barrier per K-step).  The epilogue goes through LDS so global stores are 16 bytes
-// per lane along rows.
+// Tile: 128 x 128 x 64 per workgroup of 4 waves (2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles), operands by direct-to-LDS
+// loads into an LDS image whose 16-byte chunk index is XORed with (row & 7): the MFMA fragment reads (ds_read_b128, 16 rows x
+// one chunk column per 16 lanes) are bank-conflict free.  The epilogue goes through LDS so global stores are 16 bytes per
+// lane along rows.  Launches of very many tiles take the 256 x 256 persistent form of gemm_p8.h instead.
 #pragma once
 #include "common.h"
 #include "tuning.h"
@@ -108,10 +105,28 @@ __device__ __forceinline__ int gemm_lds_off(int row, int chunk) { return row * 1
 // MODE 0: epi(m, n, acc[n..n+3]).  MODE 1 (SwiGLU): weight rows come in blocks of 32 = 16 gate rows +
 // the 16 matching up rows; epi(m, j, act[j..j+3]) receives bf16(bf16(silu(bf16 g)) * bf16 u) for the
 // N/2 fused outputs (QuantizedTextDecoder.swift:132-137).
-template <class ALoad, class Epi, int MODE>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw,
-                                                                int M, int N, int K, Epi epi) {
-    __shared__ __attribute__((aligned(16))) char smem[2][2][GEMM_BM * 128];   // [buf][A|B][row*128B]
+//
+// Operands are staged with direct-to-LDS loads (global_load_lds_dwordx4): no VGPR round trip and no ds_write_b128 (LDS
+// stores run at ~79 B/clk/CU on gfx950 and were the busiest pipe of the first, register-staged loop, removed in round 2).
+// One wave instruction fills 1 KiB of LDS linearly = 8 tile rows; the XOR chunk swizzle moves to the per-lane SOURCE address
+// (lane l of an 8-row group reads chunk (l%8) ^ (l/8)), the fragment reads keep the same swizzle.  Masked chunks (row tail,
+// K tail, conv padding taps) read a 16-byte block of zeros.
+//
+// One body, two kernels:
+//   NBUF = 2  gemm_nt_glds_kernel   64 KiB, tile k+1 in flight during the MFMAs of tile k, one barrier per K-step; 2 workgroups
+//             per CU: the form for launches of few tiles
+//   NBUF = 1  gemm_nt_glds1_kernel  ONE 32 KiB buffer, two barriers per K-step, no software double buffering: 4-5 workgroups
+//             fit a CU and the overlap of loads with MFMAs comes from the other resident workgroups: the form for launches of
+//             many tiles (and 256 x 256 tiles for launches of very many: gemm_p8.h)
+// Every form sums an output in the same k order: bit-identical results (tests/test_gpu_gemm.py).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <class ALoad, class Epi, int MODE, int NBUF>
+__device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBUF][A|B][128 rows x 128 B] */, const ALoad& aload,
+                                                 const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, const Epi& epi,
+                                                 const bf16_t* __restrict__ zeros) {
+    constexpr int OPB = GEMM_BM * 128;                  // bytes of one operand image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order: consecutive tile ids (sharing an A row panel) land on one XCD's L2
@@ -124,129 +139,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(ALoad aload, cons
     }
     const int m0 = (bid / nbx) * GEMM_BM, n0 = (bid % nbx) * GEMM_BN;
 
-    const int sc = tid & 7, sr = tid >> 3;             // staged chunk column / first staged row
-    typename ALoad::Row arow[4];
-    const bf16_t* wrow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        arow[i] = aload.row_init(m0 + sr + 32 * i);
-        int n = n0 + sr + 32 * i;
-        wrow[i] = n < N ? Wt + (long)n * ldw : nullptr;
-    }
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-        const int k = kt * GEMM_BK + sc * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = aload.load(arow[i], k);
-            rb[i] = (wrow[i] && k < K) ? *reinterpret_cast<const uint4*>(wrow[i] + k) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int off = gemm_lds_off(sr + 32 * i, sc);
-            *reinterpret_cast<uint4*>(&smem[buf][0][off]) = ra[i];
-            *reinterpret_cast<uint4*>(&smem[buf][1][off]) = rb[i];
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int fr = lane & 15, fc = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) gload(kt + 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            mfma_bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][0][gemm_lds_off(wm * 64 + i * 16 + fr, fc + 4 * s)]);
-                b[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][1][gemm_lds_off(wn * 64 + i * 16 + fr, fc + 4 * s)]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nkt) lstore(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue through LDS: wave-private 64x64 f32 image, then 16-byte row stores -----------
-    float* ct = reinterpret_cast<float*>(&smem[0][0][0]) + wave * (64 * 64);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
-    __syncthreads();
-    if (MODE == 0) {
-        const int er = lane >> 4, ec = (lane & 15) * 4;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            int row = it * 4 + er;
-            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + ec;
-            if (m < M && n < N) {
-                float4 v = *reinterpret_cast<const float4*>(&ct[row * 64 + ec]);
-                epi(m, n, v);
-            }
-        }
-    } else {
-        const int er = lane >> 3, e4 = (lane & 7) * 4, blk = e4 >> 4, e = e4 & 15;
-#pragma unroll 4
-        for (int it = 0; it < 8; ++it) {
-            int row = it * 8 + er;
-            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + blk * 32;     // first gate row of the block
-            if (m < M && n < N) {
-                float4 g = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + e]);
-                float4 u = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + 16 + e]);
-                float4 v;
-                v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
-                v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
-                epi(m, n / 2 + e, v);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Same tiling, operands staged with direct-to-LDS loads (global_load_lds_dwordx4): no VGPR round trip and no
-// ds_write_b128 (LDS stores run at ~79 B/clk/CU on gfx950 and were the busiest pipe of the register-staged
-// loop).  One wave instruction fills 1 KiB of LDS linearly = 8 tile rows; the XOR chunk swizzle moves to the
-// per-lane SOURCE address (lane l of an 8-row group reads chunk (l%8) ^ (l/8)), the fragment reads keep the
-// same swizzle.  Masked chunks (row tail, K tail, conv padding taps) read a 16-byte block of zeros.
-// ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-template <class ALoad, class Epi, int MODE>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw,
-                                                                     int M, int N, int K, Epi epi,
-                                                                     const bf16_t* __restrict__ zeros) {
-    __shared__ __attribute__((aligned(1024))) char smem[2][2][GEMM_BM * 128];   // [buf][A|B][row*128B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nbx = (N + GEMM_BN - 1) / GEMM_BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int m0 = (bid / nbx) * GEMM_BM, n0 = (bid % nbx) * GEMM_BN;
-
     // staging: wave w, instruction i covers tile rows (w*4 + i)*8 .. +7; lane -> (row + lane/8, LDS slot lane%8)
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;              // source chunk = slot ^ (row & 7), rows are 8-aligned per group
@@ -266,8 +158,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload,
             const bf16_t* pa = aload.addr(arow[i], k);
             const bf16_t* pb = (wrow[i] && k < K) ? wrow[i] + k : nullptr;
             const int off = (wave * 4 + i) * 1024;      // wave-uniform LDS base of this instruction
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa ? pa : zeros), (lds_ptr_t)&smem[buf][0][off], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb ? pb : zeros), (lds_ptr_t)&smem[buf][1][off], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa ? pa : zeros), (lds_ptr_t)&smem[(buf * 2 + 0) * OPB + off], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb ? pb : zeros), (lds_ptr_t)&smem[(buf * 2 + 1) * OPB + off], 16, 0, 0);
         }
     };
 
@@ -278,20 +170,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload,
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA completion is tracked by vmcnt only
-    __syncthreads();
     const int fr = lane & 15, fc = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);       // in flight during this tile's MFMAs
+    auto mfma_tile = [&](int cur) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             mfma_bf16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][0][gemm_lds_off(wm * 64 + i * 16 + fr, fc + 4 * s)]);
-                b[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[cur][1][gemm_lds_off(wn * 64 + i * 16 + fr, fc + 4 * s)]);
+                a[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[(cur * 2 + 0) * OPB + gemm_lds_off(wm * 64 + i * 16 + fr, fc + 4 * s)]);
+                b[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[(cur * 2 + 1) * OPB + gemm_lds_off(wn * 64 + i * 16 + fr, fc + 4 * s)]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -299,149 +186,62 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload,
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt+1 has landed (this wave's part) ...
-        __syncthreads();                                // ... and every wave's part after the barrier
-    }
-
-    float* ct = reinterpret_cast<float*>(&smem[0][0][0]) + wave * (64 * 64);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
-    __syncthreads();
-    if (MODE == 0) {
-        const int er = lane >> 4, ec = (lane & 15) * 4;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            int row = it * 4 + er;
-            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + ec;
-            if (m < M && n < N) {
-                float4 v = *reinterpret_cast<const float4*>(&ct[row * 64 + ec]);
-                epi(m, n, v);
-            }
-        }
-    } else {
-        const int er = lane >> 3, e4 = (lane & 7) * 4, blk = e4 >> 4, e = e4 & 15;
-#pragma unroll 4
-        for (int it = 0; it < 8; ++it) {
-            int row = it * 8 + er;
-            int m = m0 + wm * 64 + row, n = n0 + wn * 64 + blk * 32;
-            if (m < M && n < N) {
-                float4 g = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + e]);
-                float4 u = *reinterpret_cast<const float4*>(&ct[row * 64 + blk * 32 + 16 + e]);
-                float4 v;
-                v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
-                v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
-                epi(m, n / 2 + e, v);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same tile with ONE 32 KiB LDS buffer (two barriers per K-step, no software double buffering): 4-5 workgroups fit
-// a CU instead of 2, and the overlap of loads with MFMAs comes from the other resident workgroups.
-// ------------------------------------------------------------------------------------------------
-template <class ALoad, class Epi, int MODE>
-__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_glds1_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw,
-                                                                     int M, int N, int K, Epi epi,
-                                                                     const bf16_t* __restrict__ zeros) {
-    __shared__ __attribute__((aligned(1024))) char smem[1][2][GEMM_BM * 128];   // ONE buffer: [A|B][row*128B] = 32 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nbx = (N + GEMM_BN - 1) / GEMM_BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int m0 = (bid / nbx) * GEMM_BM, n0 = (bid % nbx) * GEMM_BN;
-
-    // staging: wave w, instruction i covers tile rows (w*4 + i)*8 .. +7; lane -> (row + lane/8, LDS slot lane%8)
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;              // source chunk = slot ^ (row & 7), rows are 8-aligned per group
-    typename ALoad::Row arow[4];
-    const bf16_t* wrow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + srow;
-        arow[i] = aload.row_init(m0 + r);
-        const int n = n0 + r;
-        wrow[i] = n < N ? Wt + (long)n * ldw : nullptr;
-    }
-    auto stage = [&](int buf, int kt) {
-        const int k = kt * GEMM_BK + schunk * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16_t* pa = aload.addr(arow[i], k);
-            const bf16_t* pb = (wrow[i] && k < K) ? wrow[i] + k : nullptr;
-            const int off = (wave * 4 + i) * 1024;      // wave-uniform LDS base of this instruction
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa ? pa : zeros), (lds_ptr_t)&smem[buf][0][off], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb ? pb : zeros), (lds_ptr_t)&smem[buf][1][off], 16, 0, 0);
-        }
     };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = (K + GEMM_BK - 1) / GEMM_BK;
-    const int fr = lane & 15, fc = lane >> 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        stage(0, kt);
+    if constexpr (NBUF == 2) {
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA completion is tracked by vmcnt only
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            mfma_bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[0][0][gemm_lds_off(wm * 64 + i * 16 + fr, fc + 4 * s)]);
-                b[i] = *reinterpret_cast<const mfma_bf16x8*>(&smem[0][1][gemm_lds_off(wn * 64 + i * 16 + fr, fc + 4 * s)]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);       // in flight during this tile's MFMAs
+            mfma_tile(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt+1 has landed (this wave's part) ...
+            __syncthreads();                                // ... and every wave's part after the barrier
         }
-        __syncthreads();                                // every wave is done with the tile before it is overwritten
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            stage(0, kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            mfma_tile(0);
+            __syncthreads();                                // every wave is done with the tile before it is overwritten
+        }
     }
 
-    // epilogue in two 32-column halves: the wave's staging image is 64 rows x 32 floats = 8 KiB (4 waves = the 32 KiB)
-    float* ct = reinterpret_cast<float*>(&smem[0][0][0]) + wave * (64 * 32);
+    // epilogue through LDS so that global accesses are 16 bytes per lane along rows: the wave's 64 x 64 result in
+    // HALVES passes of 64 x (64 / HALVES) floats (one pass with 64 KiB of LDS, two 32-column halves with 32 KiB)
+    constexpr int HALVES = NBUF == 2 ? 1 : 2, CW = 64 / HALVES;
+    float* ct = reinterpret_cast<float*>(smem) + wave * (64 * CW);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < HALVES; ++h) {
         if (h) __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int jj = 0; jj < 4 / HALVES; ++jj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * 32 + jj * 16 + fr] = acc[i][2 * h + jj][r];
+                for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * CW + jj * 16 + fr] = acc[i][(4 / HALVES) * h + jj][r];
         __syncthreads();
+        constexpr int LPR = CW / 4, RPI = 64 / LPR;         // lanes per row, rows per wave instruction
         if (MODE == 0) {
-            const int er = lane >> 3, ec = (lane & 7) * 4;
+            const int er = lane / LPR, ec = (lane % LPR) * 4;
 #pragma unroll 4
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + er;
-                const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * 32 + ec;
-                if (m < M && n < N) epi(m, n, *reinterpret_cast<const float4*>(&ct[row * 32 + ec]));
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int row = it * RPI + er;
+                const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * CW + ec;
+                if (m < M && n < N) epi(m, n, *reinterpret_cast<const float4*>(&ct[row * CW + ec]));
             }
         } else {
-            const int er = lane >> 2, e = (lane & 3) * 4;
+            // 32-column blocks = 16 gate + 16 up: a lane takes 4 fused outputs of one block
+            constexpr int BPR = CW / 32, LPB = 4, RPS = 64 / (BPR * LPB);
+            const int er = lane / (BPR * LPB), blk = (lane / LPB) % BPR, e = (lane % LPB) * 4;
 #pragma unroll 4
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 16 + er;
-                const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * 32;
+            for (int it = 0; it < 64 / RPS; ++it) {
+                const int row = it * RPS + er;
+                const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * CW + blk * 32;
                 if (m < M && n < N) {
-                    const float4 g = *reinterpret_cast<const float4*>(&ct[row * 32 + e]);
-                    const float4 u = *reinterpret_cast<const float4*>(&ct[row * 32 + 16 + e]);
+                    const float4 g = *reinterpret_cast<const float4*>(&ct[row * CW + blk * 32 + e]);
+                    const float4 u = *reinterpret_cast<const float4*>(&ct[row * CW + blk * 32 + 16 + e]);
                     float4 v;
                     v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
                     v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
@@ -450,6 +250,20 @@ __global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             }
         }
     }
+}
+
+template <class ALoad, class Epi, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N,
+                                                                     int K, Epi epi, const bf16_t* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * GEMM_BM * 128];
+    gemm_nt_128_body<ALoad, Epi, MODE, 2>(smem, aload, Wt, ldw, M, N, K, epi, zeros);
+}
+
+template <class ALoad, class Epi, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_glds1_kernel(
+    ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, Epi epi, const bf16_t* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) char smem[1 * 2 * GEMM_BM * 128];
+    gemm_nt_128_body<ALoad, Epi, MODE, 1>(smem, aload, Wt, ldw, M, N, K, epi, zeros);
 }
 
 // 256 bytes of zeros in HBM for masked direct-to-LDS chunks (one per translation unit)
@@ -471,10 +285,6 @@ inline int gemm_nbuf(int grid) {
     if (v == 1 || v == 2) return v;
     return grid >= 640 ? 1 : 2;             // 2.5 tiles per CU on the 256-CU part (686-tile launches measured faster with 1)
 }
-inline bool gemm_use_glds() {
-    return tuning().gemm_glds != 0;
-}
-
 // the 256 x 256 form (gemm_p8.h, included at the end of this header)
 template <class ALoad, class Epi, int MODE>
 __global__ void gemm_nt_p8_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, Epi epi,
@@ -496,14 +306,12 @@ inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, in
         return;
     }
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    if (gemm_use_glds() && gemm_nbuf(grid) == 1)
+    if (gemm_nbuf(grid) == 1)
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
-    else if (gemm_use_glds())
+    else
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
 }
 
 template <class ALoad, class Epi>
@@ -516,14 +324,12 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
         return;
     }
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    if (gemm_use_glds() && gemm_nbuf(grid) == 1)
+    if (gemm_nbuf(grid) == 1)
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
-    else if (gemm_use_glds())
+    else
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
 // of the last round used, or >= 8 rounds.  tuning knob gemm_p8: 0 never | 1 by this rule | 2 whenever the shape allows.
 inline bool gemm_use_p8(int M, int N) {
     const int v = tuning().gemm_p8;
-    if (v == 0 || !gemm_use_glds()) return false;
+    if (v == 0) return false;
     const long tiles = (long)cdiv(M, P8_BM) * cdiv(N, P8_BN);
     if (v == 2) return true;
     const long rounds = (tiles + 255) / 256;
