@@ -190,6 +190,7 @@ void Engine::plan_encoder() {
     int* h_cu = reinterpret_cast<int*>(hp + off);
     size_t off_cu = off;
     int img = 0, tok = 0, nwin = 0;
+    max_win_ = 0;
     h_cu[0] = 0;
     clip_tok_off_.clear();
     const long tok_stride = (long)H3_ * cfg_.conv_channels;
@@ -212,7 +213,7 @@ void Engine::plan_encoder() {
             }
             hc[img++] = m;
         }
-        for (int wl : c.windows) { h_cu[nwin + 1] = h_cu[nwin] + wl; ++nwin; }
+        for (int wl : c.windows) { h_cu[nwin + 1] = h_cu[nwin] + wl; ++nwin; max_win_ = std::max(max_win_, wl); }
     }
     n_win_ = nwin;
     if (h_cu[nwin] != n_tok_) throw std::runtime_error("window plan does not cover the packed tokens");
@@ -253,7 +254,9 @@ void Engine::run_encoder() {
     for (const EncLayerW& L : encw_.layers) {
         layernorm_f32p_launch(x, L.ln1_g, L.ln1_b, h, n_tok_, D, cfg_.ln_eps, 0, s);
         gemm_nt(ADense{h, D, n_tok_, D}, L.wqkv, D, n_tok_, 3 * D, D, EpiBiasActBf16F<0>{qkv, 3L * D, L.bqkv}, s);
-        window_attention_launch(qkv, d_cu_win_, n_win_, cfg_.enc_heads, hd, at, s);
+        // head_dim 64 (both published sizes): the transposed-score 32x32x16 kernel of the wav2vec2 path, a window = a "clip"
+        if (hd == 64 && tuning().enc_attn != 0) mha_attention_launch(qkv, d_cu_win_, n_win_, max_win_, cfg_.enc_heads, hd, at, s);
+        else window_attention_launch(qkv, d_cu_win_, n_win_, cfg_.enc_heads, hd, at, s);
         gemm_nt(ADense{at, D, n_tok_, D}, L.wo, D, n_tok_, D, D, EpiResidF32F{x, D, L.bo}, s);
         layernorm_f32p_launch(x, L.ln2_g, L.ln2_b, h, n_tok_, D, cfg_.ln_eps, 0, s);
         gemm_nt(ADense{h, D, n_tok_, D}, L.w1, D, n_tok_, F, D, EpiBiasActBf16F<1>{mid, F, L.b1}, s);

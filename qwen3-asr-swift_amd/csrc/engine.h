@@ -196,6 +196,7 @@ private:
         std::vector<EncLayerW> layers;
     } encw_;
     std::vector<std::unique_ptr<DevBuf>> fused_;   // concatenated / permuted copies built by finalize
+    int max_win_ = 0;                              // longest attention window of the planned batch
     DevBuf d_pe_;                                  // [W3][d_model] f32 sinusoid table
     int H1_ = 0, W1_ = 0, H2_ = 0, W2_ = 0, H3_ = 0, W3_ = 0;
     int max_chunks_ = 0, max_tokens_ = 0;          // capacity (whole batch)

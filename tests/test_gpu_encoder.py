@@ -148,3 +148,29 @@ def test_f32_vectors_are_not_rounded_at_load():
         assert r_exact < 1e-2 and r_exact < r_round
     finally:
         e.close()
+
+
+def test_window_attention_kernels_agree(tiny):
+    """The encoder's window attention at head_dim 64 runs on the wav2vec2 path's transposed-score kernel (a window = a clip of
+    <= 104 tokens); the 16-row kernel of round 1 stays behind the knob.  Full 0.6B width (14 heads x 64), 2 layers, a clip with
+    several windows and a ragged last one: both against the oracle, and close to each other."""
+    import dataclasses
+    cfg = dataclasses.replace(C.AUDIO_SMALL, layers=2)
+    sd = synth.synth_state_dict(cfg, dataclasses.replace(C.TEXT_SMALL, layers=1), seed=21, init="stress")
+    e = gpu_util.Engine("0.6B", max_audio_seconds=30, enc_layers=2, dec_layers=1)
+    try:
+        e.load_state_dict(sd)
+        g = torch.Generator().manual_seed(5)
+        mel = (torch.randn(128, 2350, generator=g) * 0.5).numpy()
+        outs = []
+        for knob in (0, 1):
+            e.set_tuning("enc_attn", knob)
+            got = e.encode(mel)
+            _check(got, sd, mel, cfg)
+            outs.append(got)
+        rel = np.linalg.norm(outs[0] - outs[1]) / np.linalg.norm(outs[0])
+        print(f"window attention kernels: rel-L2 {rel:.2e}")
+        assert rel < 5e-3
+    finally:
+        e.set_tuning("enc_attn", 1)
+        e.close()
