@@ -666,7 +666,7 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
     const int mt = tuning().pa_mt;          // A/B knob: row tiles per wave
     const int form = tuning().pa_form;      // A/B knob: 2 = transposed-score form
     const float scale = 1.0f / sqrtf((float)cache.hd);
-    if (form == 2 && heads == 2 * cache.kv_heads && (cache.hd == 128 || cache.hd == 32)) {
+    if (form >= 2 && heads == 2 * cache.kv_heads && (cache.hd == 128 || cache.hd == 32)) {
         const dim3 grid(cdiv(max_len, 64), cache.kv_heads, n_clips);
         if (cache.hd == 128)
             hipLaunchKernelGGL((prefill_attention2_kernel<128>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
