@@ -52,6 +52,24 @@ inline float bf16_to_f32_host(bf16_t b) {
 }
 
 __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+// two floats -> one word of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32.  Packing two separately converted values
+// costs a conversion each plus a shift and an or (found in the attention kernels' P packing: 64 instead of 16 instructions per
+// 64-key tile; the GEMM epilogues packed the same way).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_native;
+typedef __attribute__((ext_vector_type(2))) float f32x2_native;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2_native v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_native));
+}
+
+// one word of two bf16 -> its two floats
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+// RMSNorm of a bf16 pair at the reference's rounding points: bf16(weight * bf16(x * inv_rms))  (MLXFast.rmsNorm on bf16)
+__device__ __forceinline__ unsigned rmsnorm_pair_bf16(unsigned xw, unsigned ww, float inv) {
+    const unsigned t = pack_bf16x2(bf16_lo(xw) * inv, bf16_hi(xw) * inv);
+    return pack_bf16x2(bf16_lo(ww) * bf16_lo(t), bf16_hi(ww) * bf16_hi(t));
+}
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator

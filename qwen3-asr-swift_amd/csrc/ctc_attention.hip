@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void mha64_attention_kernel(const bf16_t* 
                     const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[kbk][8 * s2 + 2 * e], c_exp, -mc));
                     const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[kbk][8 * s2 + 2 * e + 1], c_exp, -mc));
                     l_run += p0 + p1;
-                    w[e] = (unsigned)f32_to_bf16(p0) | ((unsigned)f32_to_bf16(p1) << 16);
+                    w[e] = pack_bf16x2(p0, p1);
                 }
                 pf[kbk][s2] = __builtin_bit_cast(mfma_bf16x8, u);
             }

@@ -34,12 +34,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const bf16_t* __restr
         int c = lane + 64 * i;
         if (c < nch) {
             uint4 wv = reinterpret_cast<const uint4*>(w)[c];
-            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[i]);
-            const bf16_t* we = reinterpret_cast<const bf16_t*>(&wv);
-            uint4 o;
-            bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) oe[j] = f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv));
+            const uint4 o = make_uint4(rmsnorm_pair_bf16(v[i].x, wv.x, inv), rmsnorm_pair_bf16(v[i].y, wv.y, inv),
+                                       rmsnorm_pair_bf16(v[i].z, wv.z, inv), rmsnorm_pair_bf16(v[i].w, wv.w, inv));
             reinterpret_cast<uint4*>(y + (long)row * H)[c] = o;
         }
     }
@@ -136,8 +132,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     norm_rope_pair(x1a, x2a, bf16_to_f32((bf16_t)(w1 & 0xffff)), bf16_to_f32((bf16_t)(w2 & 0xffff)), inv, cs.x, sn.x, o1a, o2a);
     norm_rope_pair(x1b, x2b, bf16_to_f32((bf16_t)(w1 >> 16)), bf16_to_f32((bf16_t)(w2 >> 16)), inv, cs.y, sn.y, o1b, o2b);
     bf16_t* dst = h < heads ? qr + ((long)p * heads + h) * HD : cache.k + cache.off(sl, h - heads, ps);
-    *reinterpret_cast<unsigned*>(dst + 2 * j) = (unsigned)f32_to_bf16(o1a) | ((unsigned)f32_to_bf16(o1b) << 16);
-    *reinterpret_cast<unsigned*>(dst + HALF + 2 * j) = (unsigned)f32_to_bf16(o2a) | ((unsigned)f32_to_bf16(o2b) << 16);
+    *reinterpret_cast<unsigned*>(dst + 2 * j) = pack_bf16x2(o1a, o1b);
+    *reinterpret_cast<unsigned*>(dst + HALF + 2 * j) = pack_bf16x2(o2a, o2b);
 }
 
 // Wide form: a head lives on HD/16 lanes, each owning 8 consecutive elements of the first half and the matching 8 of the
@@ -605,11 +601,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
-                        const bf16_t p0 = f32_to_bf16(__builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j], c2, mc)));
-                        const bf16_t p1 = f32_to_bf16(__builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j + 1], c2, mc)));
-                        rs += bf16_to_f32(p0) + bf16_to_f32(p1);
+                        const unsigned pw = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j], c2, mc)),
+                                                        __builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j + 1], c2, mc)));
+                        rs += bf16_lo(pw) + bf16_hi(pw);
                         // k-slot order of the P V^T product: slots 0-3 <- keys 4g+j of the even 16-key block, 4-7 <- the odd one
-                        pk[mi][nb >> 1][(nb & 1) * 2 + j / 2] = (unsigned)p0 | ((unsigned)p1 << 16);
+                        pk[mi][nb >> 1][(nb & 1) * 2 + j / 2] = pw;
                     }
                 l_run[mi] = l_run[mi] * alpha + rs;
                 m_run[mi] = m_new;
@@ -651,8 +647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bf16_t* dst = out + ((long)(row0 + qpos) * heads + kvh * REP + mi) * HD + g * 4;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const uint2 v = make_uint2((unsigned)f32_to_bf16(o[mi][d][0] * invl) | ((unsigned)f32_to_bf16(o[mi][d][1] * invl) << 16),
-                                           (unsigned)f32_to_bf16(o[mi][d][2] * invl) | ((unsigned)f32_to_bf16(o[mi][d][3] * invl) << 16));
+                const uint2 v = make_uint2(pack_bf16x2(o[mi][d][0] * invl, o[mi][d][1] * invl), pack_bf16x2(o[mi][d][2] * invl, o[mi][d][3] * invl));
                 *reinterpret_cast<uint2*>(dst + d * 16) = v;
             }
         }
@@ -1492,9 +1487,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
-                        const bf16_t p0 = f32_to_bf16(__expf(sc[h][j] - m_new)), p1 = f32_to_bf16(__expf(sc[h][j + 1] - m_new));
-                        rsum += bf16_to_f32(p0) + bf16_to_f32(p1);
-                        pk[h * 2 + j / 2] = (unsigned)p0 | ((unsigned)p1 << 16);
+                        const unsigned pw = pack_bf16x2(__expf(sc[h][j] - m_new), __expf(sc[h][j + 1] - m_new));
+                        rsum += bf16_lo(pw) + bf16_hi(pw);
+                        pk[h * 2 + j / 2] = pw;
                     }
                 l_run = l_run * alpha + rsum;
                 m_run = m_new;

@@ -286,11 +286,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
             uint4 o = xr[i];
             if constexpr (PRO == QPRO_RMSNORM) {
                 const uint4 nw = nwr[i];
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
-                const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
-                bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) oe[j] = f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv));
+                o = make_uint4(rmsnorm_pair_bf16(xr[i].x, nw.x, inv), rmsnorm_pair_bf16(xr[i].y, nw.y, inv),
+                               rmsnorm_pair_bf16(xr[i].z, nw.z, inv), rmsnorm_pair_bf16(xr[i].w, nw.w, inv));
             }
             *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
             const bf16_t* oe = reinterpret_cast<const bf16_t*>(&o);
@@ -593,16 +590,14 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
                 const uint4 nw = nwr[i];
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
-                const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
-                uint4 o;
-                bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
+                uint4 o = make_uint4(0, 0, 0, 0);
+                if (live)
+                    o = make_uint4(rmsnorm_pair_bf16(xr[i].x, nw.x, inv), rmsnorm_pair_bf16(xr[i].y, nw.y, inv),
+                                   rmsnorm_pair_bf16(xr[i].z, nw.z, inv), rmsnorm_pair_bf16(xr[i].w, nw.w, inv));
+                // the group sum in the order of the per-element loop this replaces: ((((((e0 + e1) + e2) + e3) + ...
                 float p = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    oe[j] = live ? f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv)) : (bf16_t)0;
-                    p += bf16_to_f32(oe[j]);
-                }
+                p += bf16_lo(o.x); p += bf16_hi(o.x); p += bf16_lo(o.y); p += bf16_hi(o.y);
+                p += bf16_lo(o.z); p += bf16_hi(o.z); p += bf16_lo(o.w); p += bf16_hi(o.w);
                 *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
                 p = lane_sum8(p);
                 if ((scol & 7) == 0) s_xs[((scol + TPR * i) >> 3) * (NB * 16) + r] = p;

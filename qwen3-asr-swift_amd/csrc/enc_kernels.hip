@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
         for (int c = 0; c < 4; ++c) {
             float a = ow < cm.w1 ? gelu_erf(acc[2 * c]) : 0.0f;
             float b = ow < cm.w1 ? gelu_erf(acc[2 * c + 1]) : 0.0f;
-            pk[c] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+            pk[c] = pack_bf16x2(a, b);
         }
         o.x = pk[0]; o.y = pk[1]; o.z = pk[2]; o.w = pk[3];
         *reinterpret_cast<uint4*>(orow + (long)ow * C + c0) = o;

@@ -345,8 +345,8 @@ struct epi_has_pre<E, std::void_t<typename E::Pre>> { static constexpr bool valu
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     uint2 o;
-    o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-    o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    o.x = pack_bf16x2(v.x, v.y);
+    o.y = pack_bf16x2(v.z, v.w);
     return o;
 }
 __device__ __forceinline__ float4 unpack_bf16x4(uint2 u) {
