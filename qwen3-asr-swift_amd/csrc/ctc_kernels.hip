@@ -185,9 +185,69 @@ void w2v_frame_info_launch(const int* frame_off, const int* n_frames, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm over rows of f32 with f32 affine parameters -> bf16 (optionally through exact GELU): one wave per row
+// LayerNorm over rows of f32 with f32 affine parameters -> bf16 / f32 (optionally through GELU).  A wave owns RPW consecutive
+// rows and requests all of them before it reduces the first (VPR float4 per lane and row, RPW * VPR = 8 in registers: 4 rows at
+// D <= 512, 2 at <= 1024, 1 at <= 2048); the row statistics are DPP / permlane wave sums, not ds_bpermute shuffles.  Two-pass
+// variance (sum of squared deviations), f32 throughout, like the reference's MLXNN.LayerNorm on f32.
+// Generic fallback (one row per wave, guards per float4): D not a multiple of 256.
 // ------------------------------------------------------------------------------------------------
 constexpr int LNF_MAXV = 8;      // float4 per lane: D <= 2048
+
+template <int ACT, typename OUT>
+__device__ __forceinline__ void lnf_store(OUT* dst, float4 o) {
+    if (ACT == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
+    if constexpr (sizeof(OUT) == 4) *reinterpret_cast<float4*>(dst) = o;
+    else *reinterpret_cast<uint2*>(dst) = pack_bf16x4(o);
+}
+
+template <int ACT, typename OUT, int VPR>
+__global__ __launch_bounds__(256) void layernorm_f32p_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, OUT* __restrict__ y, int rows,
+                                                                  float eps) {
+    constexpr int RPW = LNF_MAXV / VPR, D = 256 * VPR;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    float4 v[RPW][VPR];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;             // a clamped duplicate, never stored
+        const float4* xr = reinterpret_cast<const float4*>(x + (long)row * D);
+#pragma unroll
+        for (int i = 0; i < VPR; ++i) v[r][i] = xr[lane + 64 * i];
+    }
+    float4 g[VPR], b[VPR];
+#pragma unroll
+    for (int i = 0; i < VPR; ++i) {
+        g[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+        b[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPR; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+        const float mean = lane_sum<64>(s) * (1.0f / D);
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPR; ++i) {
+            const float a = v[r][i].x - mean, c = v[r][i].y - mean, d = v[r][i].z - mean, e = v[r][i].w - mean;
+            ss += (a * a + c * c) + (d * d + e * e);
+        }
+        const float rstd = rsqrtf(lane_sum<64>(ss) * (1.0f / D) + eps);
+        if (row0 + r < rows) {
+#pragma unroll
+            for (int i = 0; i < VPR; ++i) {
+                float4 o;
+                o.x = (v[r][i].x - mean) * rstd * g[i].x + b[i].x;
+                o.y = (v[r][i].y - mean) * rstd * g[i].y + b[i].y;
+                o.z = (v[r][i].z - mean) * rstd * g[i].z + b[i].z;
+                o.w = (v[r][i].w - mean) * rstd * g[i].w + b[i].w;
+                lnf_store<ACT, OUT>(y + (long)(row0 + r) * D + (lane + 64 * i) * 4, o);
+            }
+        }
+    }
+}
 
 template <int ACT, typename OUT>
 __global__ __launch_bounds__(256) void layernorm_f32p_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -205,7 +265,7 @@ __global__ __launch_bounds__(256) void layernorm_f32p_kernel(const float* __rest
         v[i] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = lane_sum<64>(s) / (float)D;
     float ss = 0.0f;
 #pragma unroll
     for (int i = 0; i < LNF_MAXV; ++i) {
@@ -215,7 +275,7 @@ __global__ __launch_bounds__(256) void layernorm_f32p_kernel(const float* __rest
             ss += (a * a + b * b) + (c * c + d * d);
         }
     }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    const float rstd = rsqrtf(lane_sum<64>(ss) / (float)D + eps);
 #pragma unroll
     for (int i = 0; i < LNF_MAXV; ++i) {
         const int idx = lane + 64 * i;
@@ -226,26 +286,36 @@ __global__ __launch_bounds__(256) void layernorm_f32p_kernel(const float* __rest
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            if (ACT == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
-            if constexpr (sizeof(OUT) == 4) *reinterpret_cast<float4*>(y + (long)row * D + idx * 4) = o;
-            else *reinterpret_cast<uint2*>(y + (long)row * D + idx * 4) = pack_bf16x4(o);
+            lnf_store<ACT, OUT>(y + (long)row * D + idx * 4, o);
         }
     }
+}
+
+template <int ACT, typename OUT>
+static void layernorm_f32p_go(const float* x, const float* gamma, const float* beta, OUT* y, int rows, int D, float eps, hipStream_t s) {
+    if (D % 4 != 0 || D > 256 * LNF_MAXV) throw std::invalid_argument("layernorm: unsupported width");
+#define QASR_LNF(VPR_)                                                                                                         \
+    hipLaunchKernelGGL((layernorm_f32p_rows_kernel<ACT, OUT, VPR_>), dim3(cdiv(rows, 4 * (LNF_MAXV / VPR_))), dim3(256), 0, s, x, gamma, \
+                       beta, y, rows, eps)
+    if (D == 512) QASR_LNF(2);
+    else if (D == 1024) QASR_LNF(4);
+    else if (D == 2048) QASR_LNF(8);
+    else if (D == 256) QASR_LNF(1);
+    else hipLaunchKernelGGL((layernorm_f32p_kernel<ACT, OUT>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, rows, D, eps);
+#undef QASR_LNF
 }
 
 void layernorm_gelu_f32_launch(const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps,
                                hipStream_t s) {
     if (rows <= 0) return;
-    if (D % 4 != 0 || D > 256 * LNF_MAXV) throw std::invalid_argument("layernorm: unsupported width");
-    hipLaunchKernelGGL((layernorm_f32p_kernel<1, float>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, rows, D, eps);
+    layernorm_f32p_go<1, float>(x, gamma, beta, y, rows, D, eps, s);
 }
 
 void layernorm_f32p_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, int rows, int D, float eps, int act,
                            hipStream_t s) {
     if (rows <= 0) return;
-    if (D % 4 != 0 || D > 256 * LNF_MAXV) throw std::invalid_argument("layernorm: unsupported width");
-    if (act) hipLaunchKernelGGL((layernorm_f32p_kernel<1, bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, rows, D, eps);
-    else hipLaunchKernelGGL((layernorm_f32p_kernel<0, bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, rows, D, eps);
+    if (act) layernorm_f32p_go<1, bf16_t>(x, gamma, beta, y, rows, D, eps, s);
+    else layernorm_f32p_go<0, bf16_t>(x, gamma, beta, y, rows, D, eps, s);
 }
 
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n4) {
@@ -267,10 +337,17 @@ __global__ __launch_bounds__(256) void argmax_f32_kernel(const float* __restrict
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     bool bad = false;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float v = row[i];
+    auto take = [&](float v, int i) {
         bad |= !(fabsf(v) <= 3.0e38f);                     // NaN or infinity: a broken checkpoint, not a transcript
         if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    };
+    if ((n & 3) == 0 && (ld & 3) == 0) {                    // 16-byte loads (every published vocabulary: 10288)
+        for (int i = threadIdx.x * 4; i < n; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(row + i);
+            take(v.x, i); take(v.y, i + 1); take(v.z, i + 2); take(v.w, i + 3);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) take(row[i], i);
     }
     if (bad && err) atomicOr(err, 1);
     s_v[threadIdx.x] = bv;
