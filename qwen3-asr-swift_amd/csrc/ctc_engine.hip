@@ -358,9 +358,9 @@ void CtcEngine::forward(const float* const* pcm, const size_t* n, size_t Bz, std
         cast_f32_bf16_launch(x, h, (long)Ftot * D, s);
         w2v_frame_info_launch(dv_off(6), dv_n(6), B, Ftot, d_info_.as<int2>(), s);
         const int KP = cfg_.pos_kernel, cpg = D / cfg_.pos_groups;
-        for (int g = 0; g < cfg_.pos_groups; ++g)
-            gemm_nt(AGroupConv1d{h, d_info_.as<int2>(), D, cpg, KP, g, Ftot}, pos_w_ + (size_t)g * cpg * KP * cpg, (long)KP * cpg, Ftot, cpg,
-                    KP * cpg, EpiPosConv{y, x, D, pos_b_, g * cpg}, s);
+        // all groups in one launch: a group alone is 375 tiles at 300M, a third of what the chip holds at once
+        gemm_nt_groups(AGroupConv1d{h, d_info_.as<int2>(), D, cpg, KP, 0, Ftot}, pos_w_, (long)KP * cpg, (long)cpg * KP * cpg, cfg_.pos_groups,
+                       Ftot, cpg, KP * cpg, EpiPosConv{y, x, D, pos_b_, 0, cpg}, s);
         std::swap(x, y);                                     // x = frontend output
         QASR_HIP(hipEventRecord(ev_[1], s));
         // ---- transformer encoder --------------------------------------------------------------------------------

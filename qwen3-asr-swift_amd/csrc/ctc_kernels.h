@@ -46,6 +46,7 @@ struct AGroupConv1d {
     int D, cpg, KP, g, M;
     static constexpr bool no_p8 = true;   // N = D / 16 columns per launch: a 256-wide tile would be mostly padding anyway
     struct Row { const bf16_t* base; int kmin, kmax; };
+    __device__ __forceinline__ AGroupConv1d for_group(int grp) const { AGroupConv1d a = *this; a.g = grp; return a; }
     __device__ __forceinline__ Row row_init(int m) const {
         if (m >= M) return {nullptr, 0, 0};
         const int2 tl = info[m];
@@ -56,7 +57,9 @@ struct AGroupConv1d {
     }
     __device__ __forceinline__ const bf16_t* addr(const Row& r, int k) const {
         if (!r.base) return nullptr;
-        const int tap = k / cpg, ci = k - tap * cpg;
+        // k / cpg without an integer division (cpg is a run-time value, 64 / 80 / 128 in the published variants): exact for
+        // k < 2^20 with the rounded-up reciprocal, like AConv3x3s2::addr
+        const int tap = (int)__umulhi((unsigned)k, (0xffffffffu / (unsigned)cpg) + 1u), ci = k - tap * cpg;
         if (tap < r.kmin || tap >= r.kmax) return nullptr;
         return r.base + (long)tap * D + ci;
     }
@@ -108,6 +111,8 @@ struct EpiResidF32F {
 // positional encoder: y[m][col0 + n] = gelu(acc + bias[col0 + n]) + x[m][col0 + n]
 struct EpiPosConv {
     float* y; const float* x; long ld; const float* bias; int col0;
+    int cpg = 0;                                            // columns per group (for_group)
+    __device__ __forceinline__ EpiPosConv for_group(int grp) const { EpiPosConv e = *this; e.col0 = grp * cpg; return e; }
     __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
         const float4 b = *reinterpret_cast<const float4*>(bias + col0 + n);
         const float4 r = *reinterpret_cast<const float4*>(x + (long)m * ld + col0 + n);

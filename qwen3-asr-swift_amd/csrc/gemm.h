@@ -268,6 +268,17 @@ __global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     gemm_nt_128_body<ALoad, Epi, MODE, 1>(smem, aload, Wt, ldw, M, N, K, epi, zeros);
 }
 
+// Grouped form: gridDim.y independent GEMMs of one shape in ONE launch (the 16 groups of the wav2vec2 positional conv: each is
+// only 375 tiles, a third of what the chip holds at once).  The operand / epilogue functors provide for_group(g) -> the functor
+// of group g; W advances by w_group_stride elements per group.
+template <class ALoad, class Epi, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_glds1_groups_kernel(
+    ALoad aload, const bf16_t* __restrict__ Wt, long ldw, long w_group_stride, int M, int N, int K, Epi epi, const bf16_t* __restrict__ zeros) {
+    __shared__ __attribute__((aligned(1024))) char smem[1 * 2 * GEMM_BM * 128];
+    const int g = blockIdx.y;
+    gemm_nt_128_body<ALoad, Epi, MODE, 1>(smem, aload.for_group(g), Wt + (long)g * w_group_stride, ldw, M, N, K, epi.for_group(g), zeros);
+}
+
 // 256 bytes of zeros in HBM for masked direct-to-LDS chunks (one per translation unit)
 inline const bf16_t* gemm_zero_block() {
     static bf16_t* z = nullptr;
@@ -314,6 +325,15 @@ inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, in
     else
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
+}
+
+template <class ALoad, class Epi>
+inline void gemm_nt_groups(const ALoad& a, const bf16_t* Wt, long ldw, long w_group_stride, int groups, int M, int N, int K, const Epi& epi,
+                           hipStream_t s) {
+    if (M <= 0 || N <= 0 || groups <= 0) return;
+    const int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
+    hipLaunchKernelGGL((gemm_nt_glds1_groups_kernel<ALoad, Epi, 0>), dim3(grid, groups), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, w_group_stride,
+                       M, N, K, epi, gemm_zero_block());
 }
 
 template <class ALoad, class Epi>
