@@ -36,18 +36,26 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
     const int g = tid / P, c0 = (tid - g * P) * 8;
     if (g >= G) return;
     bf16_t* orow = out + (((long)img * H1 + oh) * W1) * C;
+    // the thread's 8 channels x 9 taps stay in registers for all of its pixels (they were re-read from LDS per pixel: 18
+    // ds_read_b128 beside 72 FMAs)
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wr[t][c] = s_w[t * C + c0 + c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) br[c] = s_b[c0 + c];
     for (int ow = g; ow < W1; ow += G) {
         float acc[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = s_b[c0 + c];
+        for (int c = 0; c < 8; ++c) acc[c] = br[c];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                float x = s_in[kh * (W_IN + 2) + 2 * ow + kw];
-                const float* wp = s_w + (kh * 3 + kw) * C + c0;
+                const float x = s_in[kh * (W_IN + 2) + 2 * ow + kw];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = fmaf(x, wp[c], acc[c]);
+                for (int c = 0; c < 8; ++c) acc[c] = fmaf(x, wr[kh * 3 + kw][c], acc[c]);
             }
         uint4 o;
         unsigned pk[4];
