@@ -49,6 +49,8 @@ def main():
                                                           "clips sharded, one all_gather of the padded id block per pass")
     a = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if "QASR_BENCH_DEVICE" in os.environ:                       # rehearsal of the N > 1 path on a one-GPU box (gloo, ranks share the card)
+        local = int(os.environ["QASR_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
