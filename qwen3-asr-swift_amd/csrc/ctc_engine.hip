@@ -442,6 +442,10 @@ void CtcEngine::set_pieces(const char* const* texts, const int32_t* types, size_
 void CtcEngine::load_sentencepiece(const std::string& path) {
     std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot open " + path);
+    f.seekg(0, std::ios::end);
+    const std::streamoff size = f.tellg();
+    if (size < 0 || size > (std::streamoff)(256 << 20)) throw std::runtime_error("sentencepiece model: implausible file size");   // published: 0.4 MB
+    f.seekg(0);
     std::string d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     pieces_.clear();
     size_t p = 0;
