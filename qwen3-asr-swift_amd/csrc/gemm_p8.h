@@ -27,7 +27,7 @@
 
 namespace qasr {
 
-constexpr int P8_BM = 256, P8_BN = 256, P8_THREADS = 512, P8_UNIT = 16384;
+constexpr int P8_BM = 256, P8_BN = 256, P8_THREADS = 512, P8_UNIT = 16384, P8_TM = 4;
 
 template <class E, bool HAS>
 struct epi_pre_type { struct type {}; };
@@ -43,8 +43,8 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     // Persistent workgroups (one per CU).  Workgroup ids go round the 8 XCDs, so id & 7 names the XCD; XCD x owns the x-th
-    // eighth of the tile list (column tile fastest) and its workgroups walk that range round-robin: the tiles in flight on one
-    // XCD share one or two A row panels (fetched into that L2 once) and all of W.
+    // eighth of the tile list (order: tile_rows below) and its workgroups walk that range round-robin: the tiles in flight on
+    // one XCD share a few A row panels and W column slices, each fetched into that L2 once.
     const int nbx = (N + P8_BN - 1) / P8_BN, nby = (M + P8_BM - 1) / P8_BM;
     const int ncls = gridDim.x < 8 ? gridDim.x : 8;         // a launch of fewer than 8 workgroups: one tile range each
     const int xcd = blockIdx.x % ncls, wgs_per_xcd = (gridDim.x - xcd + ncls - 1) / ncls;
@@ -60,8 +60,13 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     const bf16_t *blo[2], *bhi[2];
     int m0, n0;
     auto tile_rows = [&](int t) {
-        m0 = (t / nbx) * P8_BM;
-        n0 = (t % nbx) * P8_BN;
+        // tile list order: blocks of P8_TM row panels, column tile by column tile inside a block, panel fastest.  The 32
+        // workgroups of an XCD then run 4 panels x 8 column tiles at a time: 12 distinct operand streams behind their 32 tiles
+        // whatever N is (plain row-major order made it 1 panel x 32 column tiles = 33 streams at N = 8192, the 7B FFN-up shape).
+        const int blk = t / (P8_TM * nbx), i = t - blk * (P8_TM * nbx);
+        const int rows_in_blk = nby - blk * P8_TM < P8_TM ? nby - blk * P8_TM : P8_TM;
+        m0 = (blk * P8_TM + i % rows_in_blk) * P8_BM;
+        n0 = (i / rows_in_blk) * P8_BN;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int u = (wave * 2 + i) * 8 + srow;
