@@ -127,6 +127,22 @@ def test_reference_error_behaviour(tiny):
         m2.close()
 
 
+def test_7b_width_one_layer():
+    """BASELINE configs[3]'s geometry (Omnilingual-ASR-CTC-7B: D 2048, 32 heads x 64, FFN 8192, positional conv groups of 128
+    channels) with one transformer layer: the 256-wide GEMM tiles at K = 2048 / 8192, the grouped positional conv at N = 128,
+    32-head attention, against the oracle; a ragged batch equals the single-clip calls."""
+    cfg = dataclasses.replace(O.VARIANTS["7B"], layers=1)
+    sd = synth.synth_omnilingual_state_dict(cfg, seed=17)
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="7B", layers=1, max_batch=3, max_audio_seconds=8)
+    try:
+        _check_logits(m, sd, cfg, _wave(8, 6.4), "7B width, 1 layer")
+        clips = [_wave(k, 1.1 + 1.9 * k) for k in range(3)]
+        out = m.transcribe_batch(clips)
+        assert [m.transcribe_batch([c])[0] for c in clips] == out
+    finally:
+        m.close()
+
+
 def test_maximum_clip_length_40s():
     """The reference's cap (40 s = 640 000 samples -> 1999 frames, OmnilingualMLXModel.swift:154-159) at the 300M widths, one
     layer: the longest attention sweep (32 key tiles, 16 query blocks per head), the largest conv row tables, and one sample
