@@ -639,29 +639,44 @@ void Engine::decode_loop() {
     const int split = decode_split_env();
     const long key = ((long)batch_ << 32) | ((long)split << 24) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
     const bool use_graph_ = tuning().use_graph != 0;
-    // a knob change (qasr_set_tuning) can select other kernels: the captured step is stale then
-    if (use_graph_ && (graph_exec_ == nullptr || graph_key_ != key || graph_epoch_ != tuning().epoch)) {
-        drop_graph();
-        graph_epoch_ = tuning().epoch;
+    // steps per graph launch: the step's kernel arguments never change, so S consecutive steps are the same nodes S times; the
+    // EOS poll below happens every 8 steps, so S divides 8
+    const int gs = tuning().graph_steps;
+    const int S = (gs == 2 || gs == 4 || gs == 8) ? gs : 1;
+    auto capture = [&](int n, hipGraphExec_t* exec) {
         hipGraph_t g = nullptr;
         QASR_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         try {
-            issue_decode_step(split);
+            for (int i = 0; i < n; ++i) issue_decode_step(split);
         } catch (...) {
             (void)hipStreamEndCapture(stream_, &g);
             if (g) (void)hipGraphDestroy(g);
             throw;
         }
         QASR_HIP(hipStreamEndCapture(stream_, &g));
-        QASR_HIP(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
+        QASR_HIP(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
         QASR_HIP(hipGraphDestroy(g));
+    };
+    // a knob change (qasr_set_tuning) can select other kernels: the captured step is stale then
+    if (use_graph_ && (graph_exec_ == nullptr || graph_key_ != key || graph_epoch_ != tuning().epoch || graph_n_ != S)) {
+        drop_graph();
+        graph_epoch_ = tuning().epoch;
+        capture(1, &graph_exec_);
+        if (S > 1) capture(S, &graph_exec_n_);
+        graph_n_ = S;
         graph_key_ = key;
     }
     int h_active = batch_;
     for (int step = 0; step < max_steps; ++step) {
-        if (use_graph_) QASR_HIP(hipGraphLaunch(graph_exec_, stream_));
-        else issue_decode_step(split);
-        ++steps_done_;
+        if (use_graph_ && S > 1 && step % S == 0 && step + S <= max_steps) {
+            QASR_HIP(hipGraphLaunch(graph_exec_n_, stream_));
+            steps_done_ += S;
+            step += S - 1;
+        } else {
+            if (use_graph_) QASR_HIP(hipGraphLaunch(graph_exec_, stream_));
+            else issue_decode_step(split);
+            ++steps_done_;
+        }
         if (!cur_ignore_eos_ && (step % 8 == 7)) {
             QASR_HIP(hipMemcpyAsync(&h_active, gstate_.n_active, sizeof(int), hipMemcpyDeviceToHost, stream_));
             QASR_HIP(hipStreamSynchronize(stream_));

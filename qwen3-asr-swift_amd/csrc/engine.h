@@ -248,6 +248,8 @@ private:
     int steps_done_ = 0;
     // decode-step graph, keyed by (B, max_tokens, ignore_eos)
     hipGraphExec_t graph_exec_ = nullptr;
+    hipGraphExec_t graph_exec_n_ = nullptr;                      // the same step captured tuning().graph_steps times in a row
+    int graph_n_ = 0;
     long graph_key_ = -1;
     unsigned graph_epoch_ = 0;                                 // tuning().epoch the graph was captured under
     int* d_err_flag_ = nullptr;                                // device word: set when a greedy step sees a non-finite best logit

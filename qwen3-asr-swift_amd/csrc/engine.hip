@@ -59,6 +59,7 @@ Engine::Engine(const qasr_config& cfg) : cfg_(cfg) {
 Engine::~Engine() {
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_exec_n_) (void)hipGraphExecDestroy(graph_exec_n_);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     if (fork_ev_) (void)hipEventDestroy(fork_ev_);
     for (int i = 0; i < 3; ++i) {
@@ -84,6 +85,8 @@ void Engine::set_tensor(const std::string& name, const void* host, int dtype, co
 
 void Engine::drop_graph() {
     if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    if (graph_exec_n_) { (void)hipGraphExecDestroy(graph_exec_n_); graph_exec_n_ = nullptr; }
+    graph_n_ = 0;
     graph_key_ = -1;
 }
 

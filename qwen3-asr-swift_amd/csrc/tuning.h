@@ -26,6 +26,7 @@ struct Tuning {
     int lmh_diag = 0;        // diagnostic: LM-head loop without LDS reads / MFMA (wrong results, timing only)
     int decode_split = 1;    // decode row groups on parallel graph branches
     int decode_gran = 16;    // rows per such group (multiple)
+    int graph_steps = 8;     // decode steps captured per hipGraph launch: 1 | 2 | 4 | 8 (8 = the EOS poll interval: -0.4 ms of decode at 32 clips)
     int use_graph = 1;       // 0: issue every decode step eagerly (no hipGraph replay)
     int da_stamps = 0, gemv_stamps = 0, stamps_insitu = 0;   // diagnostics of qasr_kernel_probe (make DIAG=1 builds)
     unsigned epoch = 0;

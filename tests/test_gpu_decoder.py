@@ -137,6 +137,16 @@ def test_no_graph_equals_graph(tiny):
         eng.set_tuning("use_graph", 1)
     c = eng.transcribe_batch(clips, max_tokens=9, ignore_eos=True)
     assert a == b == c
+    # several steps per graph launch (default 8) against one step per launch, token budgets around the multiples of 8 and with
+    # the EOS rule live (the poll interval is 8 steps: a multi-step graph must stop at the same token)
+    for mt in (8, 9, 17, 26):
+        for ignore in (True, False):
+            got = {}
+            for gs in (1, 4, 8):
+                eng.set_tuning("graph_steps", gs)
+                got[gs] = eng.transcribe_batch(clips, max_tokens=mt, ignore_eos=ignore)
+            eng.set_tuning("graph_steps", 8)
+            assert got[1] == got[4] == got[8], (mt, ignore)
 
 
 def test_forced_decode_capacity(tiny):
