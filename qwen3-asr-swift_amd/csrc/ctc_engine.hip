@@ -303,17 +303,26 @@ void CtcEngine::forward(const float* const* pcm, const size_t* n, size_t Bz, std
         long L = (long)n[b];
         for (int i = 0; i < 7; ++i) { L = conv_len(L, i); lv_n(i)[b] = (int)L; }
     }
-    // caller memory (pageable) -> pinned staging on a few threads, whole clips each (61 MB at 32 x 30 s)
+    // caller memory (pageable) -> pinned staging -> HBM in up to four slices of whole clips: a slice is staged on a few threads and
+    // its H2D copy queued at once, so staging of slice i + 1 overlaps the copy of slice i (61 MB at 32 x 30 s)
     {
         const int nthr = off > (1L << 20) ? std::min(B, 8) : 1;
-        auto copy_range = [&](int b0, int b1) {
-            for (int b = b0; b < b1; ++b) std::memcpy(h_pcm_.as<float>() + h_off[b], pcm[b], n[b] * sizeof(float));
-        };
-        if (nthr <= 1) copy_range(0, B);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthr; ++t) pool.emplace_back(copy_range, B * t / nthr, B * (t + 1) / nthr);
-            for (auto& th : pool) th.join();
+        const int nsl = off > (8L << 20) ? std::min(B, 4) : 1;
+        for (int sidx = 0; sidx < nsl; ++sidx) {
+            const int s0 = B * sidx / nsl, s1 = B * (sidx + 1) / nsl, nb = s1 - s0;
+            auto copy_range = [&](int b0, int b1) {
+                for (int b = b0; b < b1; ++b) std::memcpy(h_pcm_.as<float>() + h_off[b], pcm[b], n[b] * sizeof(float));
+            };
+            const int t_n = std::min(nthr, nb);
+            if (t_n <= 1) copy_range(s0, s1);
+            else {
+                std::vector<std::thread> pool;
+                for (int t = 0; t < t_n; ++t) pool.emplace_back(copy_range, s0 + nb * t / t_n, s0 + nb * (t + 1) / t_n);
+                for (auto& th : pool) th.join();
+            }
+            const long e0 = h_off[s0], e1 = s1 < B ? h_off[s1] : off;
+            QASR_HIP(hipMemcpyAsync(d_pcm_.as<float>() + e0, h_pcm_.as<float>() + e0, (size_t)(e1 - e0) * sizeof(float), hipMemcpyHostToDevice,
+                                    stream_));
         }
     }
     int max_n0 = 0, max_frames = 0;
@@ -326,7 +335,6 @@ void CtcEngine::forward(const float* const* pcm, const size_t* n, size_t Bz, std
     const int Ftot = lv_off(6)[B];
     const size_t meta_bytes = (size_t)B * (sizeof(long) + sizeof(int)) + (size_t)7 * (2 * B + 1) * sizeof(int);
     hipStream_t s = stream_;
-    QASR_HIP(hipMemcpyAsync(d_pcm_.p, h_pcm_.p, off * sizeof(float), hipMemcpyHostToDevice, s));
     QASR_HIP(hipMemcpyAsync(d_meta_.p, h_meta_.p, meta_bytes, hipMemcpyHostToDevice, s));
     const long* d_off = d_meta_.as<long>();
     const int* d_ns = reinterpret_cast<const int*>(d_off + B);
