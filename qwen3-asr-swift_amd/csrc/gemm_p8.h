@@ -6,16 +6,18 @@
 //   * A K-tile (64 wide) is staged as four 16 KiB units of 128 rows: A-lo / A-hi = the first / second 64 rows of each wave
 //     row-group's 128, B-lo / B-hi = the first / second 32 columns of each wave column-group's 64.  Ring = 2 K-tiles x 4 units.
 //   * A K-tile is consumed in four phases, one 64 x 32 quadrant of the wave's output each (16 MFMAs 16x16x32):
-//       P0 reads A-lo (8 fragments) + B-lo (4), quadrant (lo, lo)      P1 reads B-hi (4), quadrant (lo, hi)
-//       P2 reads A-hi (8), quadrant (hi, hi)                           P3 reads nothing, quadrant (hi, lo): B-lo stays in registers
-//     so a unit's last LDS read is P0 (A-lo, B-lo), P1 (B-hi) or P2 (A-hi) of its tile.
+//       P0 reads A-lo (8 fragments), quadrant (lo, lo)                 P1 reads B-hi (4), quadrant (lo, hi)
+//       P2 reads A-hi (8), quadrant (hi, hi)                           P3 reads B-lo of the NEXT K-tile (4), quadrant (hi, lo)
+//     -- B-lo of a tile is read one phase before the tile starts (into the B-hi registers, handed over by 16 moves), which evens the LDS read bursts out to 8 / 4 / 8 / 4 per phase (12 / 4 / 8 / 0 before).
+//     A unit's last LDS read is P0 (A-lo), P1 (B-hi), P2 (A-hi) of its tile or P3 of the tile before (B-lo).
 //   * Every phase issues ONE unit (2 direct-to-LDS instructions per wave), always >= 2 phases after the last read of the
 //     slot it overwrites and >= 5 phases before its first read:
 //       P0(t): B-hi(t+1)   P1(t): A-hi(t+1)   P2(t): A-lo(t+2)   P3(t): B-lo(t+2)
-//     and then waits vmcnt(8): everything but the four youngest units has landed, i.e. every unit the NEXT phase reads.
-//   * Phase = [LDS reads, unit issue, vmcnt(8)] s_barrier [lgkmcnt(0), 16 MFMAs] s_barrier.  The wave row-group 1 runs one
+//     and then waits vmcnt(6): everything but the three youngest units has landed, i.e. every unit the NEXT phase reads
+//     (B-lo(t+1), issued in P3(t-1), is read in P3(t); three units in flight run as fast as four: profiles/r02_ab_p8_*).
+//   * Phase = [LDS reads, unit issue, vmcnt(6)] s_barrier [lgkmcnt(0), 16 MFMAs] s_barrier.  The wave row-group 1 runs one
 //     barrier behind group 0 (it takes one extra barrier before the loop, group 0 one after it): on every SIMD one wave is in
-//     its MFMA segment while its partner reads LDS.  RAW: a unit is read in phase p + 1 after the vmcnt(8) of phase p of
+//     its MFMA segment while its partner reads LDS.  RAW: a unit is read in phase p + 1 after the vmcnt(6) of phase p of
 //     BOTH groups (intervals 2p and 2p + 1) and the barrier that ends interval 2p + 1.  WAR: a unit issued in phase p (interval
 //     2p at the earliest) overwrites data last read in phase <= p - 2, whose reads retired (lgkmcnt(0)) by interval 2p - 2.
 //   * K-tiles past the end stage zeros (the operand functors return no address for k >= K): the wait counts stay uniform.
@@ -124,17 +126,16 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     stage_b(U_BLO, 1, blo);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
 
     mfma_bf16x8 af[4][2], bl[2][2], bh[2][2];
-#define P8_READ_A(UNIT)                                                                                                      \
+#define P8_READ_A(TILE, UNIT)                                                                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s = 0; s < 2; ++s)                               \
-        af[i][s] = *reinterpret_cast<const mfma_bf16x8*>(&tile[(UNIT) * P8_UNIT + (a_off[i] ^ (s << 6))]);
-#define P8_READ_B(DST, UNIT)                                                                                                 \
+        af[i][s] = *reinterpret_cast<const mfma_bf16x8*>(&(TILE)[(UNIT) * P8_UNIT + (a_off[i] ^ (s << 6))]);
+#define P8_READ_B(DST, TILE, UNIT)                                                                                           \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s = 0; s < 2; ++s)                               \
-        DST[j][s] = *reinterpret_cast<const mfma_bf16x8*>(&tile[(UNIT) * P8_UNIT + (b_off[j] ^ (s << 6))]);
+        DST[j][s] = *reinterpret_cast<const mfma_bf16x8*>(&(TILE)[(UNIT) * P8_UNIT + (b_off[j] ^ (s << 6))]);
 #define P8_SYNC_IN()                                                                                                         \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                         \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                         \
     __builtin_amdgcn_s_barrier();                                                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                       \
@@ -147,33 +148,46 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     __builtin_amdgcn_s_setprio(0);                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                                       \
     __builtin_amdgcn_s_barrier();
-
+    // One K-tile = four phases.  bl holds B-lo of this tile on entry (read during the previous tile's last phase, or before the
+    // loop); bh receives B-hi in P1 and, in P3 -- whose MFMAs use bl -- B-lo of the NEXT tile from the other half of the ring:
+    // LDS reads per phase 8 / 4 / 8 / 4.  16 register moves per tile hand it over (two tile bodies with swapped register roles
+    // spilled).
+    {
+        const char* tile0 = &smem[0];
+        P8_READ_B(bl, tile0, U_BLO)                         // B-lo of K-tile 0 (landed: the wait + barrier above)
+    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind group 0 from here on
     for (int kt = 0; kt < nkt; ++kt) {
         const char* tile = &smem[(kt & 1) * 4 * P8_UNIT];
+        const char* tnext = &smem[((kt + 1) & 1) * 4 * P8_UNIT];
         // P0
-        P8_READ_B(bl, U_BLO)
-        P8_READ_A(U_ALO)
+        P8_READ_A(tile, U_ALO)
         stage_b(U_BHI, kt + 1, bhi);
         P8_SYNC_IN()
         P8_MFMA(bl, 0, 0)
         P8_SYNC_OUT()
         // P1
-        P8_READ_B(bh, U_BHI)
+        P8_READ_B(bh, tile, U_BHI)
         stage_a(U_AHI, kt + 1, ahi);
         P8_SYNC_IN()
         P8_MFMA(bh, 0, 1)
         P8_SYNC_OUT()
         // P2
-        P8_READ_A(U_AHI)
+        P8_READ_A(tile, U_AHI)
         stage_a(U_ALO, kt + 2, alo);
         P8_SYNC_IN()
         P8_MFMA(bh, 1, 1)
         P8_SYNC_OUT()
         // P3
+        P8_READ_B(bh, tnext, U_BLO)
         stage_b(U_BLO, kt + 2, blo);
         P8_SYNC_IN()
         P8_MFMA(bl, 1, 0)
         P8_SYNC_OUT()
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) bl[j][s2] = bh[j][s2];
     }
 #undef P8_READ_A
 #undef P8_READ_B
