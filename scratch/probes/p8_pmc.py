@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-ROOT = "/root/repo"
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "qwen3-asr-swift_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import gpu_util
