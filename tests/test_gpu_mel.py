@@ -46,3 +46,24 @@ def test_mel_silence_and_dropped_frame_max(eng):
     y = np.zeros(1760, np.float32) + 1e-4
     y[-100:] = 0.9                                                    # max lives in the dropped frame
     assert np.abs(eng.mel(y) - omel.log_mel(y)).max() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["synth", "speech", "short"])
+def test_device_mel_vs_independent_golden(name):
+    """The DEVICE mel against tests/golden/hf_mel.npz directly (transformers.audio_utils' STFT + slaney filterbank driven by the
+    reference's 512-point definition, float64; see tests/test_oracle_mel.py): engine at fft_scale = 1.0, the reference's tail
+    (max over all frames incl. the dropped one, clamp, affine, drop-last) applied to the golden's raw log10 spectrogram."""
+    import os
+    from conftest import GOLDEN
+    G = np.load(os.path.join(GOLDEN, "hf_mel.npz"))
+    pcm, raw = G["wave/" + name], G["raw_log10/" + name].astype(np.float64)
+    want = (np.maximum(raw, raw.max() - 8.0) * 0.25 + 1.0)[:, :-1]
+    e = gpu_util.Engine("tiny", max_audio_seconds=4, fft_scale=1.0)
+    try:
+        got = e.mel(pcm)
+    finally:
+        e.close()
+    assert got.shape == want.shape
+    err = float(np.abs(got - want).max())
+    print(f"{name}: max |device - transformers| = {err:.2e}")
+    assert err < 1e-4
