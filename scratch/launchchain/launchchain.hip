@@ -24,6 +24,45 @@ __global__ __launch_bounds__(512) void k_touch(const float4* __restrict__ in, fl
     if (threadIdx.x < 16) out[blockIdx.x * 16 + threadIdx.x] = a;   // 256 B per workgroup
 }
 
+
+// gemv-like launch: 64 KiB of the predecessor's output (dependent), then this launch's own 32 KiB-per-workgroup weight slice from a
+// region no launch has read for > 1 GB (HBM, not the caches).  pf: a ninth wave touches one dword per 128 B line of the NEXT launch's
+// slice of the same workgroup index (same XCD -> same L2); wfirst: issue the own weight loads together with the X loads instead of
+// after X was consumed.
+template <int pf, int wfirst>
+__global__ __launch_bounds__(576) void k_gemv(const float4* in, float4* out, const float4* W, const int* Wnext) {   // no __restrict__: the asm memory barriers must order the loads
+    const int tid = threadIdx.x;
+    if (tid >= 512) {      // ninth wave: the only one whose loads may stay outstanding for an HBM round trip (vmcnt is in-order per wave)
+        if (pf) {
+            const int* pp = Wnext + (size_t)blockIdx.x * 8192 + (tid - 512) * 32;
+            const int p = pp[0] ^ pp[64 * 32] ^ pp[128 * 32] ^ pp[192 * 32];
+            if (p == 0x7fffffff) out[0].x = 1.f;
+        }
+        return;
+    }
+    float4 x[8], w[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = in[tid + i * 512];
+    const float4* wp = W + (size_t)blockIdx.x * 2048 + tid;
+    if (wfirst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = wp[j * 512];
+    }
+    asm volatile("" ::: "memory");
+    float4 a = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a.x += x[i].x; a.y += x[i].y; a.z += x[i].z; a.w += x[i].w; }
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) :: "memory");     // X is consumed before anything below is issued
+    if (!wfirst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = wp[j * 512];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a.x += w[j].x; a.y += w[j].y; a.z += w[j].z; a.w += w[j].w; }
+    if (tid < 16) out[blockIdx.x * 16 + tid] = a;
+}
+
 int main() {
     const int N = 142, R = 50;
     float4 *a, *b, *big;
@@ -50,5 +89,33 @@ int main() {
             fflush(stdout);
             CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
         }
+
+    {
+        const size_t slice = (size_t)256 * 32768;                 // 8 MB per launch
+        char* Wb; CK(hipMalloc(&Wb, slice * (N + 1))); CK(hipMemset(Wb, 0, slice * (N + 1)));
+        for (int wfirst = 0; wfirst < 2; ++wfirst)
+            for (int pf = 0; pf < 2; ++pf) {
+                hipGraph_t g; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int i = 0; i < N; ++i)
+                {
+                    auto kf = wfirst ? (pf == 0 ? k_gemv<0, 1> : k_gemv<1, 1>) : (pf == 0 ? k_gemv<0, 0> : k_gemv<1, 0>);
+                    hipLaunchKernelGGL(kf, dim3(256), dim3(576), 0, s, (i & 1) ? b : a, (i & 1) ? a : b,
+                                       (const float4*)(Wb + slice * i), (const int*)(Wb + slice * ((i + 1) % N)));
+                }
+                CK(hipStreamEndCapture(s, &g));
+                CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                for (int w = 0; w < 3; ++w) CK(hipGraphLaunch(ge, s));
+                CK(hipStreamSynchronize(s));
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int r = 0; r < R; ++r) CK(hipGraphLaunch(ge, s));
+                CK(hipStreamSynchronize(s));
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                printf("gemv    grid 256 x 512, 8 MB of cold weights per launch, weights %s X, next-slice touch %s: %.2f us per launch\n",
+                       wfirst ? "with " : "after", pf == 0 ? "none" : "by a ninth wave", us / (R * N));
+                fflush(stdout);
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+            }
+    }
     return 0;
 }
