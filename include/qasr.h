@@ -89,8 +89,9 @@ typedef struct qasr_options {
     const int32_t* language_ids;       /* tokenised "language XX" hint (:228-232) or NULL */
     int32_t n_language;
     /* Qwen3DecodingOptions (Qwen3ASR.swift:13-51).  All zero = greedy fast path (isGreedyFastPath, :300-304).
-     * Any non-default value selects the reference's slow path: logits come back to the host every step and
-     * pickNextToken (:449-520) runs on the CPU. */
+     * Any non-default value selects the reference's slow path (generateSlow): the f32 logits of every row are written each
+     * step and pickNextToken (:449-520) runs on them -- on the device by default, on the host (qasr_pick_next_token) with the
+     * tuning knob device_sampler = 0; same tokens at temperature 0, same uniform stream (seed) otherwise. */
     float repetition_penalty;          /* 0 or 1.0 = off; HF sign-aware penalty on already generated ids */
     int32_t no_repeat_ngram_size;      /* 0 = off */
     float temperature;                 /* 0 = argmax; > 0 = Gumbel-max sampling */

@@ -629,6 +629,15 @@ void Engine::issue_decode_step(int split) {
                            d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), stream_, decw_.quant ? &decw_.embed_raw : nullptr);
 }
 
+// Non-default decoding options on the device: pick from the f32 logits the LM head wrote (dec_kernels.h: sampler_pick_launch), then
+// the same bookkeeping + embedding gather as the greedy path.  The row partials reuse the front of the LM head's partial buffers.
+void Engine::sample_and_finalize(int advance_ctx) {
+    sampler_pick_launch(d_logits_.as<float>(), cfg_.vocab, gstate_, batch_, opt_rep_penalty_, opt_ngram_, opt_temperature_,
+                        (unsigned long long)opt_seed_, d_part_val_.as<float>(), d_part_idx_.as<int>(), stream_);
+    greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), 1, gstate_, batch_, advance_ctx, decw_.embed,
+                           d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), stream_, decw_.quant ? &decw_.embed_raw : nullptr);
+}
+
 // Greedy loop (Qwen3ASR.swift:344-389): token 0 comes from the prompt pass; every further token costs
 // one decode step.  The step is captured once into a hipGraph (all per-step state -- ctx_len, tokens,
 // finished -- lives in HBM, so the kernel arguments never change) and replayed.  With natural EOS the
@@ -637,8 +646,27 @@ void Engine::decode_loop() {
     const int max_steps = cur_max_tokens_ - 1;
     if (max_steps <= 0) return;
     const int split = decode_split_env();
-    const long key = ((long)batch_ << 32) | ((long)split << 24) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
+    // sampled: the slow path's step (logits of every row, pickNextToken, bookkeeping) entirely on the device; the options are kernel
+    // arguments of the captured step, so they are part of the graph key
+    const bool sampled = slow_path_;
+    long key = ((long)batch_ << 32) | ((long)split << 24) | ((long)cur_max_tokens_ << 1) | (cur_ignore_eos_ ? 1 : 0);
+    if (sampled) {
+        unsigned long long h = 0x9e3779b97f4a7c15ull;
+        auto mixin = [&](unsigned long long v) { h = (h ^ v) * 0xbf58476d1ce4e5b9ull; h ^= h >> 29; };
+        unsigned u;
+        std::memcpy(&u, &opt_rep_penalty_, 4); mixin(u);
+        std::memcpy(&u, &opt_temperature_, 4); mixin(u);
+        mixin((unsigned long long)(unsigned)opt_ngram_);
+        mixin((unsigned long long)opt_seed_);
+        key ^= (long)(h | (1ull << 62));
+    }
     const bool use_graph_ = tuning().use_graph != 0;
+    auto issue_step = [&]() {
+        if (sampled) {
+            run_decode_step(true, false, 0, batch_, stream_, true);
+            sample_and_finalize(1);
+        } else issue_decode_step(split);
+    };
     // steps per graph launch: the step's kernel arguments never change, so S consecutive steps are the same nodes S times; the
     // EOS poll below happens every 8 steps, so S divides 8
     const int gs = tuning().graph_steps;
@@ -647,7 +675,7 @@ void Engine::decode_loop() {
         hipGraph_t g = nullptr;
         QASR_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
         try {
-            for (int i = 0; i < n; ++i) issue_decode_step(split);
+            for (int i = 0; i < n; ++i) issue_step();
         } catch (...) {
             (void)hipStreamEndCapture(stream_, &g);
             if (g) (void)hipGraphDestroy(g);
@@ -674,7 +702,7 @@ void Engine::decode_loop() {
             step += S - 1;
         } else {
             if (use_graph_) QASR_HIP(hipGraphLaunch(graph_exec_, stream_));
-            else issue_decode_step(split);
+            else issue_step();
             ++steps_done_;
         }
         if (!cur_ignore_eos_ && (step % 8 == 7)) {
@@ -773,11 +801,13 @@ void Engine::batch_run() {
     run_encoder();
     QASR_HIP(hipEventRecord(ev_[2], s));
     run_prefill(slow_path_);
+    const bool host_sampler = slow_path_ && tuning().device_sampler == 0;
     if (!slow_path_)
         greedy_finalize_launch(d_part_val_.as<float>(), d_part_idx_.as<int>(), n_parts_, gstate_, batch_, 0, decw_.embed,
                                d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), s, decw_.quant ? &decw_.embed_raw : nullptr);
+    else if (!host_sampler) sample_and_finalize(0);
     QASR_HIP(hipEventRecord(ev_[3], s));
-    if (slow_path_) decode_loop_slow();
+    if (host_sampler) decode_loop_slow();
     else decode_loop();
     QASR_HIP(hipEventRecord(ev_[4], s));
 }

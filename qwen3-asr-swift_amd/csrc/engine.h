@@ -158,6 +158,7 @@ private:
     void run_prefill(bool want_logits);
     void run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s, bool with_head);
     void issue_decode_step(int split);
+    void sample_and_finalize(int advance_ctx);
     int decode_group_rows() const;
     GreedyState greedy_rows(int r0) const;
     RopeRows rope_rows(int r0) const;

@@ -15,7 +15,7 @@ const Entry kEntries[] = {
     {"pa_form", &Tuning::pa_form}, {"pa_mt", &Tuning::pa_mt}, {"qknr_wide", &Tuning::qknr_wide},
     {"enc_attn", &Tuning::enc_attn}, {"mha_form", &Tuning::mha_form}, {"gemm_p8", &Tuning::gemm_p8}, {"gemm_nbuf", &Tuning::gemm_nbuf},
     {"lmh_q_ring", &Tuning::lmh_q_ring}, {"lmh_grid", &Tuning::lmh_grid}, {"lmh_diag", &Tuning::lmh_diag},
-    {"decode_split", &Tuning::decode_split}, {"decode_gran", &Tuning::decode_gran}, {"graph_steps", &Tuning::graph_steps}, {"use_graph", &Tuning::use_graph},
+    {"decode_split", &Tuning::decode_split}, {"decode_gran", &Tuning::decode_gran}, {"graph_steps", &Tuning::graph_steps}, {"use_graph", &Tuning::use_graph}, {"device_sampler", &Tuning::device_sampler},
     {"da_stamps", &Tuning::da_stamps}, {"gemv_stamps", &Tuning::gemv_stamps}, {"stamps_insitu", &Tuning::stamps_insitu},
 };
 }  // namespace

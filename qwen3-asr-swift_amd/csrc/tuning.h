@@ -28,6 +28,8 @@ struct Tuning {
     int decode_gran = 16;    // rows per such group (multiple)
     int graph_steps = 8;     // decode steps captured per hipGraph launch: 1 | 2 | 4 | 8 (8 = the EOS poll interval: -0.4 ms of decode at 32 clips)
     int use_graph = 1;       // 0: issue every decode step eagerly (no hipGraph replay)
+    int device_sampler = 1;  // non-default decoding options: 1 pickNextToken on the device (no host round trip per step) | 0 logits to the host,
+                             // csrc/sampler.cpp picks (the reference's own structure)
     int da_stamps = 0, gemv_stamps = 0, stamps_insitu = 0;   // diagnostics of qasr_kernel_probe (make DIAG=1 builds)
     unsigned epoch = 0;
 };

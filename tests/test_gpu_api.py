@@ -348,6 +348,46 @@ def test_slow_path_decoding_options(model, sd):
     assert a != c or a != greedy
 
 
+def test_device_sampler_equals_host_sampler(model):
+    """The non-default decoding options run pickNextToken on the device by default (sampler_pick_kernel: no logits round
+    trip per step); `device_sampler = 0` keeps the reference's structure (logits to the host, csrc/sampler.cpp).  Both see
+    the same logits, so with temperature 0 the token streams are identical -- repetition penalty over the distinct ids,
+    n-gram bans (n = 1 bans every generated id), their combination, natural EOS and a ragged batch.  With temperature > 0
+    the uniform stream is the same counter-based splitmix64 on both sides and only logf may differ in the last ulp."""
+    lib = model.lib
+    clips = [synth.synth_waveform(0, 2.0), synth.synth_waveform(1, 0.7), synth.synth_waveform(2, 3.1)]
+
+    def run(dev, **kw):
+        assert lib.qasr_set_tuning(b"device_sampler", dev) == 0
+        try:
+            return model.transcribe_batch(clips, **kw)
+        finally:
+            assert lib.qasr_set_tuning(b"device_sampler", 1) == 0
+
+    for opts in (dict(repetition_penalty=1.5), dict(no_repeat_ngram_size=1), dict(no_repeat_ngram_size=2),
+                 dict(repetition_penalty=1.3, no_repeat_ngram_size=3), dict(repetition_penalty=0.5)):
+        for ignore in (True, False):
+            for mt in (1, 2, 19):
+                a = run(1, max_tokens=mt, ignore_eos=ignore, **opts)
+                b = run(0, max_tokens=mt, ignore_eos=ignore, **opts)
+                assert a == b, (opts, ignore, mt)
+                if ignore:
+                    assert all(len(t) == mt for t in a)
+    uni = run(1, max_tokens=19, ignore_eos=True, no_repeat_ngram_size=1)
+    assert all(len(set(t)) == len(t) for t in uni)                     # n = 1: no id twice
+    # temperature: same seed -> same stream on both sides; a differing pick is allowed only where logf's last ulp can decide
+    same = total = 0
+    for seed in (3, 4, 5):
+        a = run(1, max_tokens=12, ignore_eos=True, temperature=0.8, seed=seed, repetition_penalty=1.1)
+        b = run(0, max_tokens=12, ignore_eos=True, temperature=0.8, seed=seed, repetition_penalty=1.1)
+        assert a == run(1, max_tokens=12, ignore_eos=True, temperature=0.8, seed=seed, repetition_penalty=1.1)
+        for x, y in zip(a, b):
+            n = next((i for i, (p, q) in enumerate(zip(x, y)) if p != q), len(x))   # streams may part after a flipped pick
+            same += n
+            total += len(x)
+    assert same >= 0.9 * total, (same, total)
+
+
 def test_streaming_asr_batched_equals_sequential(model):
     """StreamingASR mirror (qasr/streaming.py) on the engine: bursts of signal separated by silence, an energy VAD in
     place of Silero (a separate model, out of scope); all segments in one ragged batch == one transcribe per segment."""
