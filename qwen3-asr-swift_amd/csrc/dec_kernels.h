@@ -118,12 +118,6 @@ struct GreedyState {
     int ignore_eos;
     int vocab;          // ids outside [0, vocab) (all-NaN logits) are clamped to 0 so the gather cannot fault, and *err is set
 };
-// Device-side pickNextToken (Qwen3ASR.swift:449-520) for the non-default decoding options: one workgroup per batch row edits the
-// row's f32 logits in place -- HF sign-aware repetition penalty over the distinct generated ids, then the no-repeat-n-gram bans --
-// and scans it (with temperature > 0: logits / T + Gumbel noise from the same counter-based splitmix64 stream as csrc/sampler.cpp,
-// row b, call lens[b] * V + i) for the first maximum.  Writes one (value, index) partial per row for greedy_finalize (n_parts = 1).
-void sampler_pick_launch(float* logits, int V, GreedyState st, int B, float repetition_penalty, int ngram, float temperature,
-                         unsigned long long seed, float* part_val, int* part_idx, hipStream_t s);
 // rope rows of the next decode position, one per batch row (cos_rows/sin_rows [B][half]), copied from the
 // position-indexed tables by greedy_finalize so decode attention does not chain ctx_len -> table lookup
 struct RopeRows {

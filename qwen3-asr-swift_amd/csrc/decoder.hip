@@ -12,6 +12,7 @@
 //   prompt pass activations are packed over all clips: row p = cu[clip] + position
 //   decode activations are [batch row][features]
 #include "engine.h"
+#include "dec_sampler.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -629,7 +630,7 @@ void Engine::issue_decode_step(int split) {
                            d_dx_.as<bf16_t>(), cfg_.hidden, rope_rows(0), stream_, decw_.quant ? &decw_.embed_raw : nullptr);
 }
 
-// Non-default decoding options on the device: pick from the f32 logits the LM head wrote (dec_kernels.h: sampler_pick_launch), then
+// Non-default decoding options on the device: pick from the f32 logits the LM head wrote (dec_sampler.h: sampler_pick_launch), then
 // the same bookkeeping + embedding gather as the greedy path.  The row partials reuse the front of the LM head's partial buffers.
 void Engine::sample_and_finalize(int advance_ctx) {
     sampler_pick_launch(d_logits_.as<float>(), cfg_.vocab, gstate_, batch_, opt_rep_penalty_, opt_ngram_, opt_temperature_,
