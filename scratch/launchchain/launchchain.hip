@@ -63,6 +63,52 @@ __global__ __launch_bounds__(576) void k_gemv(const float4* in, float4* out, con
     if (tid < 16) out[blockIdx.x * 16 + tid] = a;
 }
 
+
+// ---- does warming a K/V-sized stream into the Infinity Cache from the idle time of GEMV-shaped launches pay? ----------------------------
+// One "layer" = 4 GEMV-shaped launches (k_gemv2: as k_gemv, plus a ninth wave that touches a quarter of the NEXT stream's 61.5 MB, one dword
+// per 128-B line, after sleeping `delay` x 64 cycles so that the X reads go first) + 1 streaming launch that reads its 61.5 MB once
+// (256 workgroups x 240 KiB).  28 layers per graph, all buffers distinct (1.7 GB of streams, 0.9 GB of weights).
+template <int pf>
+__global__ __launch_bounds__(576) void k_gemv2(const float4* in, float4* out, const float4* W, const int* S, int part, int delay) {
+    const int tid = threadIdx.x;
+    if (tid >= 512) {
+        if (pf) {
+            if (delay > 0) for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(1);
+            // quarter `part` of the stream: 61.5 MB / 4 = 15.4 MB = 120 K lines; workgroup b touches lines b*64 + lane, stride gridDim.x*64
+            const int lane = tid - 512;
+            const long lines = (long)256 * 245760 / 128 / 4, base = (long)part * lines;
+            int acc = 0;
+            for (long l = (long)blockIdx.x * 64 + lane; l < lines; l += (long)gridDim.x * 64) acc ^= S[(base + l) * 32];
+            if (acc == 0x7fffffff) out[0].x = 1.f;
+        }
+        return;
+    }
+    float4 x[8], w[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = in[tid + i * 512];
+    asm volatile("" ::: "memory");
+    float4 a = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a.x += x[i].x; a.y += x[i].y; a.z += x[i].z; a.w += x[i].w; }
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) :: "memory");
+    const float4* wp = W + (size_t)blockIdx.x * 2048 + tid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = wp[j * 512];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a.x += w[j].x; a.y += w[j].y; a.z += w[j].z; a.w += w[j].w; }
+    if (tid < 16) out[blockIdx.x * 16 + tid] = a;
+}
+
+__global__ __launch_bounds__(512) void k_stream(const float4* in, float4* out, const float4* S) {
+    const int tid = threadIdx.x;
+    float4 a = in[tid];                                                    // dependent on the predecessor
+    const float4* p = S + (size_t)blockIdx.x * (245760 / 16) + tid;        // 240 KiB per workgroup = 15360 float4 = 30 per thread
+#pragma unroll 10
+    for (int i = 0; i < 30; ++i) { const float4 v = p[i * 512]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (tid < 16) out[blockIdx.x * 16 + tid] = a;
+}
+
 int main() {
     const int N = 142, R = 50;
     float4 *a, *b, *big;
@@ -116,6 +162,56 @@ int main() {
                 fflush(stdout);
                 CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
             }
+    }
+
+    {
+        const int L = 28;
+        const size_t slice = (size_t)256 * 32768, stream = (size_t)256 * 245760;
+        char *Wb, *Sb;
+        CK(hipMalloc(&Wb, slice * 4 * L)); CK(hipMemset(Wb, 0, slice * 4 * L));
+        CK(hipMalloc(&Sb, stream * L)); CK(hipMemset(Sb, 0, stream * L));
+        for (int mode = 0; mode < 4; ++mode) {            // 0 no prefetch | 1 prefetch, no delay | 2 delay 16 x 64 cycles | 3 delay 32 x 64
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int flip = 0;
+            for (int l = 0; l < L; ++l) {
+                for (int j = 0; j < 4; ++j) {
+                    auto kf = mode == 0 ? k_gemv2<0> : k_gemv2<1>;
+                    hipLaunchKernelGGL(kf, dim3(256), dim3(576), 0, s, flip ? b : a, flip ? a : b, (const float4*)(Wb + slice * (4 * l + j)),
+                                       (const int*)(Sb + stream * l), j, mode == 2 ? 16 : mode == 3 ? 32 : 0);
+                    flip ^= 1;
+                }
+                hipLaunchKernelGGL(k_stream, dim3(256), dim3(512), 0, s, flip ? b : a, flip ? a : b, (const float4*)(Sb + stream * l));
+                flip ^= 1;
+            }
+            CK(hipStreamEndCapture(s, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            for (int w = 0; w < 3; ++w) CK(hipGraphLaunch(ge, s));
+            CK(hipStreamSynchronize(s));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < R; ++r) CK(hipGraphLaunch(ge, s));
+            CK(hipStreamSynchronize(s));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            const char* names[4] = {"no warm-up", "ninth wave warms the next stream, at once", "... after 16 x 64 cycles", "... after 32 x 64 cycles"};
+            printf("layer   4 gemv-shaped launches + one 61.5 MB stream, %s: %.2f us per layer\n", names[mode], us / (R * L));
+            fflush(stdout);
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        }
+        // the streaming launch alone, back to back on distinct buffers
+        {
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_stream, dim3(256), dim3(512), 0, s, (l & 1) ? b : a, (l & 1) ? a : b, (const float4*)(Sb + stream * l));
+            CK(hipStreamEndCapture(s, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            for (int w = 0; w < 3; ++w) CK(hipGraphLaunch(ge, s));
+            CK(hipStreamSynchronize(s));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < R; ++r) CK(hipGraphLaunch(ge, s));
+            CK(hipStreamSynchronize(s));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            printf("stream  61.5 MB per launch from HBM, alone: %.2f us per launch\n", us / (R * L));
+        }
     }
     return 0;
 }
