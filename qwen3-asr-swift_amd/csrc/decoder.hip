@@ -13,6 +13,7 @@
 //   decode activations are [batch row][features]
 #include "engine.h"
 #include "dec_sampler.h"
+#include "dec_gemv_wide.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -551,6 +552,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         // float checkpoint: fragment-major bf16 images; quantised checkpoint: packed 4 / 8-bit images (dec_quant.h)
         auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) {
             if (decw_.quant) decode_gemv_q_launch(epi, a, qi, norm_w, cfg_.rms_eps, h, s);
+            else if (!norm_w && tuning().gemv_wide && decode_gemv_wide_supported(epi, a)) decode_gemv_wide_launch(epi, a, s);   // K = 6144 (1.7B)
             else decode_gemv_fused_launch(epi, a, norm_w, norm_w ? cfg_.rms_eps : 0.f, norm_w ? h : nullptr, s);
         };
         a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;

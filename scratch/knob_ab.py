@@ -2,7 +2,7 @@
 """In-process A/B of tuning knobs on the bench workload (one engine, one resident batch, variants interleaved round by
 round; median and min of the stage times over the rounds -- cdna_hip_programming.md rule 24).
 
-usage: python scratch/knob_ab.py [--batch 32] [--seconds 30] [--tokens 128] [--rounds 5] name=k1:v1,k2:v2 ...
+usage: python scratch/knob_ab.py [--batch 32] [--seconds 30] [--tokens 128] [--rounds 5] [--bits 16] [--preset 0.6B] name=k1:v1,k2:v2 ...
    e.g. python scratch/knob_ab.py base= nt=gemv_nt:1 dant=da_nt:1 both=gemv_nt:1,da_nt:1 pf=kv_prefetch:1
 """
 import argparse
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=128)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--bits", type=int, default=16, choices=[16, 8, 4], help="16 = bf16 decoder, 4 / 8 = MLX-quantised, packed")
+    ap.add_argument("--preset", default="0.6B", choices=["0.6B", "1.7B"])
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     variants = []
@@ -35,10 +36,11 @@ def main():
             k, _, val = kv.partition(":")
             knobs[k] = int(val)
         variants.append((name, knobs))
-    sd = synth.synth_state_dict(QC.AUDIO_SMALL, QC.TEXT_SMALL, seed=0, init="hf")
+    large = a.preset == "1.7B"
+    sd = synth.synth_state_dict(QC.AUDIO_LARGE if large else QC.AUDIO_SMALL, QC.TEXT_LARGE if large else QC.TEXT_SMALL, seed=0, init="hf")
     if a.bits != 16:
         sd = synth.quantize_state_dict(sd, a.bits)
-    m = Qwen3ASRModel.from_state_dict(sd, preset="0.6B", bits=a.bits, max_batch=a.batch, max_audio_seconds=int(np.ceil(a.seconds)),
+    m = Qwen3ASRModel.from_state_dict(sd, preset=a.preset, bits=a.bits, max_batch=a.batch, max_audio_seconds=int(np.ceil(a.seconds)),
                                       max_new_tokens=448)
     clips = [synth.synth_waveform(k, a.seconds) for k in range(a.batch)]
     m.batch_begin(clips, max_tokens=a.tokens, ignore_eos=True)

@@ -136,7 +136,8 @@ def test_30s_clips_batch8_properties():
 def test_1p7b_preset_geometry():
     """Qwen3-ASR-1.7B preset (encoder 1024/24/16 -> 2048, decoder hidden 2048 / inter 6144; AudioEncoder.swift:51-68,
     Configuration.swift:89-100) with 4 decoder/encoder layers to keep the CPU oracle affordable: exercises the
-    K = 2048 tuned GEMVs, the K = 6144 generic fallback and the 2048-wide persistent LM head."""
+    K = 2048 tuned GEMVs, the K = 6144 down-projection (two-phase form of dec_gemv_wide.hip, and the generic kernel it replaced:
+    the same teacher-forced check passes with `gemv_wide = 0`) and the 2048-wide persistent LM head."""
     import dataclasses
     a = dataclasses.replace(C.AUDIO_LARGE, layers=4)
     t = dataclasses.replace(C.TEXT_LARGE, layers=4)
@@ -162,9 +163,29 @@ def test_1p7b_preset_geometry():
                 assert logits[tk] >= logits.max() - _tol(logits.numpy()), (i, tk)
                 if i + 1 < len(toks):
                     logits = decoder.decode_step(tk, model.W, t, state, P.DEVICE)
+            # the kernel the K = 6144 matrix took before: the forced decode's logits of the two agree within the logit bound
+            eng.prefill_logits(got_emb)
+            lg_wide = eng.decode_forced(toks[:4])
+            eng.set_tuning("gemv_wide", 0)
+            try:
+                eng.prefill_logits(got_emb)
+                lg_gen = eng.decode_forced(toks[:4])
+            finally:
+                eng.set_tuning("gemv_wide", 1)
+            assert np.abs(lg_wide - lg_gen).max() <= _tol(lg_gen) and np.linalg.norm(lg_wide - lg_gen) / np.linalg.norm(lg_gen) < 2e-2
         four = [synth.synth_waveform(k, 1.0 + 0.5 * k) for k in range(4)]
         b4 = eng.transcribe_batch(four, max_tokens=5, ignore_eos=True)
         assert b4[1] == eng.transcribe_batch([four[1]], max_tokens=5, ignore_eos=True)[0]
+    finally:
+        eng.close()
+    # 18 rows: two 16-row groups on gridDim.y, the second with two live rows; rows never interact
+    eng = gpu_util.Engine("1.7B", max_batch=18, max_audio_seconds=2, max_new_tokens=8, enc_layers=4, dec_layers=4)
+    try:
+        eng.load_state_dict(sd)
+        clips = [synth.synth_waveform(k, 0.6 + 0.05 * k) for k in range(18)]
+        b18 = eng.transcribe_batch(clips, max_tokens=4, ignore_eos=True)
+        for k in (0, 15, 16, 17):
+            assert b18[k] == eng.transcribe_batch([clips[k]], max_tokens=4, ignore_eos=True)[0], k
     finally:
         eng.close()
 
