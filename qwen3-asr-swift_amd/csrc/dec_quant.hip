@@ -197,13 +197,17 @@ struct DecGemvQArgs {
     float eps;
 };
 
-template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI>
+// KPH > 1 (K = 6144, the 1.7B preset's down-projection: 16 rows x 12 KiB do not fit the LDS): the activation rows pass through the
+// same LDS image in KPH column phases of K / KPH columns; all packed weights and all rows are requested up front as before.
+template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI, int KPH = 1>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int BLK = BITS == 4 ? 128 : 64, GPB = BLK / 64;
-    constexpr int K = KBW * WAVES * BLK, G = K / 64, KCH = K / 8, XSTRIDE = 2 * K + 16;
+    constexpr int KH = KBW * WAVES * BLK;                                      // columns per phase
+    constexpr int K = KH * KPH, G = K / 64, GH = KH / 64, KCH = KH / 8, XSTRIDE = 2 * KH + 16;
     constexpr int TPR = WAVES * 64 / 16, XI = KCH / TPR;
     static_assert(TPR % 8 == 0 && TPR <= 64 && KCH % TPR == 0, "row staging geometry");
+    static_assert(KPH == 1 || PRO == QPRO_COPY, "column phases: no RMSNorm prologue (the row statistic needs the whole row)");
     DecGemvArgs a = a2.g;
     {
         const int r0 = blockIdx.y * 16;
@@ -214,18 +218,18 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
     const int n0 = blockIdx.x * 16 * NT;
     char* s_x = dsm;                                                          // [16][XSTRIDE] bf16
-    float* s_xs = reinterpret_cast<float*>(dsm + 16 * XSTRIDE);               // [G][16] group sums
-    float* s_red = s_xs + G * 16;                                             // [WAVES][NT][16 batch][16 n]
+    float* s_xs = reinterpret_cast<float*>(dsm + 16 * XSTRIDE);               // [GH][16] group sums (of the phase in LDS)
+    float* s_red = s_xs + GH * 16;                                            // [WAVES][NT][16 batch][16 n]
     const int srow = tid / TPR, scol = tid % TPR;
     // ---- 1. activation loads (clamped row, zeroed by a select) --------------------------------------------
-    uint4 xr[XI];
+    uint4 xr[KPH][XI];
+    const bf16_t* xp = a.X + (long)(srow < a.B ? srow : 0) * K + scol * 8;
     {
-        const bf16_t* xp = a.X + (long)(srow < a.B ? srow : 0) * K + scol * 8;
 #pragma unroll
-        for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+        for (int i = 0; i < XI; ++i) xr[0][i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
         if (srow >= a.B) {
 #pragma unroll
-            for (int i = 0; i < XI; ++i) xr[i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < XI; ++i) xr[0][i] = make_uint4(0, 0, 0, 0);
         }
     }
     // norm weights: requested here, all at once (left inside the staging loop the compiler issues them one by one, each
@@ -236,23 +240,34 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
         for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
     }
     // ---- 2. every packed weight block of this wave + the scales / biases of its groups --------------------
-    uint4 wq[NT][KBW];
-    float sc[NT][KBW][GPB], bi[NT][KBW][GPB];
+    // block index of (phase kp, i): kp * (KH / BLK) + wave + WAVES * i, stored at [kp * KBW + i]
+    uint4 wq[NT][KBW * KPH];
+    float sc[NT][KBW * KPH][GPB], bi[NT][KBW * KPH][GPB];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const long tile = n0 / 16 + t;
         const uint32_t* qp = a2.qp + (tile * (K / BLK) * 64 + lane) * 4;
 #pragma unroll
-        for (int i = 0; i < KBW; ++i) wq[t][i] = *reinterpret_cast<const uint4*>(qp + (long)(wave + WAVES * i) * 256);
+        for (int kp = 0; kp < KPH; ++kp)
 #pragma unroll
-        for (int i = 0; i < KBW; ++i)
+            for (int i = 0; i < KBW; ++i)
+                wq[t][kp * KBW + i] = *reinterpret_cast<const uint4*>(qp + (long)(kp * (KH / BLK) + wave + WAVES * i) * 256);
 #pragma unroll
-            for (int h = 0; h < GPB; ++h) {
-                const int g = (wave + WAVES * i) * GPB + h;
-                sc[t][i][h] = sb_at<SBF32>(a2.sb, ((tile * 2 + 0) * 16 + fr) * G + g);
-                bi[t][i][h] = eff_bias<BITS>(sc[t][i][h], sb_at<SBF32>(a2.sb, ((tile * 2 + 1) * 16 + fr) * G + g));
-            }
+        for (int kp = 0; kp < KPH; ++kp)
+#pragma unroll
+            for (int i = 0; i < KBW; ++i)
+#pragma unroll
+                for (int h = 0; h < GPB; ++h) {
+                    const int g = (kp * (KH / BLK) + wave + WAVES * i) * GPB + h;
+                    sc[t][kp * KBW + i][h] = sb_at<SBF32>(a2.sb, ((tile * 2 + 0) * 16 + fr) * G + g);
+                    bi[t][kp * KBW + i][h] = eff_bias<BITS>(sc[t][kp * KBW + i][h], sb_at<SBF32>(a2.sb, ((tile * 2 + 1) * 16 + fr) * G + g));
+                }
     }
+    // the later phases' activation rows: behind the weight requests, in registers long before their phase
+#pragma unroll
+    for (int kp = 1; kp < KPH; ++kp)
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xr[kp][i] = *reinterpret_cast<const uint4*>(xp + kp * KH + i * TPR * 8);
     // the requests above stay above: left to itself the scheduler sinks them below the RMSNorm reduction (five dependent
     // cross-lane steps), i.e. the weights are asked for a microsecond late
     __builtin_amdgcn_sched_barrier(0);
@@ -266,60 +281,70 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
                 rsd[t][0] = *reinterpret_cast<const uint2*>(a.out + (long)(erow < a.B ? erow : 0) * a.N + n0 + t * 16 + eq * 4);
         }
     }
-    // ---- 3. activation rows -> LDS (+ RMSNorm), group sums of the staged values -----------------------------
-    {
-        char* xrow = s_x + (size_t)srow * XSTRIDE + scol * 16;
-        float inv = 0.0f;
-        if constexpr (PRO == QPRO_RMSNORM) {
-            float ss = 0.0f;
-#pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
-            }
-            ss = lane_sum<TPR>(ss);
-            inv = rsqrtf(ss / (float)K + a2.eps);
-        }
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            uint4 o = xr[i];
-            if constexpr (PRO == QPRO_RMSNORM) {
-                const uint4 nw = nwr[i];
-                o = make_uint4(rmsnorm_pair_bf16(xr[i].x, nw.x, inv), rmsnorm_pair_bf16(xr[i].y, nw.y, inv),
-                               rmsnorm_pair_bf16(xr[i].z, nw.z, inv), rmsnorm_pair_bf16(xr[i].w, nw.w, inv));
-            }
-            *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
-            const bf16_t* oe = reinterpret_cast<const bf16_t*>(&o);
-            float p = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p += bf16_to_f32(oe[j]);
-            // chunk c = scol + TPR * i belongs to group c / 8: the 8 chunks of a group sit on 8 adjacent lanes
-            p = lane_sum8(p);
-            if ((scol & 7) == 0) s_xs[((scol + TPR * i) >> 3) * 16 + srow] = p;
-        }
-    }
-    __syncthreads();
-    // ---- 4. per group: two MFMAs from zero, then scale / bias on the vector unit ----------------------------
+    // ---- 3. + 4. per column phase: activation rows -> LDS (+ RMSNorm), group sums of the staged values; then per group two MFMAs from
+    // zero and scale / bias on the vector unit ---------------------------------------------------------------------------------------
     f32x4 tot[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) tot[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < KBW; ++i) {
-        const int blk = wave + WAVES * i;
+    for (int kp = 0; kp < KPH; ++kp) {
+        if (kp > 0) {
+            __syncthreads();                                 // the previous phase's LDS reads are done
+            if (srow >= a.B) {
 #pragma unroll
-        for (int h = 0; h < GPB; ++h) {
-            const int g = blk * GPB + h;
-            const f32x4 xs = *reinterpret_cast<const f32x4*>(s_xs + g * 16 + fc * 4);
-            const uint4 x0 = *reinterpret_cast<const uint4*>(s_x + (size_t)fr * XSTRIDE + ((g * 2 + 0) * 32 + fc * 8) * 2);
-            const uint4 x1 = *reinterpret_cast<const uint4*>(s_x + (size_t)fr * XSTRIDE + ((g * 2 + 1) * 32 + fc * 8) * 2);
+                for (int i = 0; i < XI; ++i) xr[kp][i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        {
+            char* xrow = s_x + (size_t)srow * XSTRIDE + scol * 16;
+            float inv = 0.0f;
+            if constexpr (PRO == QPRO_RMSNORM) {
+                float ss = 0.0f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x0), frag_of<BITS>(wq[t][i], 2 * h + 0), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x1), frag_of<BITS>(wq[t][i], 2 * h + 1), acc, 0, 0, 0);
+                for (int i = 0; i < XI; ++i) {
+                    const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[kp][i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tot[t][j] += sc[t][i][h] * acc[j] + bi[t][i][h] * xs[j];
+                    for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
+                }
+                ss = lane_sum<TPR>(ss);
+                inv = rsqrtf(ss / (float)K + a2.eps);
+            }
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                uint4 o = xr[kp][i];
+                if constexpr (PRO == QPRO_RMSNORM) {
+                    const uint4 nw = nwr[i];
+                    o = make_uint4(rmsnorm_pair_bf16(o.x, nw.x, inv), rmsnorm_pair_bf16(o.y, nw.y, inv),
+                                   rmsnorm_pair_bf16(o.z, nw.z, inv), rmsnorm_pair_bf16(o.w, nw.w, inv));
+                }
+                *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
+                const bf16_t* oe = reinterpret_cast<const bf16_t*>(&o);
+                float p = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p += bf16_to_f32(oe[j]);
+                // chunk c = scol + TPR * i belongs to group c / 8: the 8 chunks of a group sit on 8 adjacent lanes
+                p = lane_sum8(p);
+                if ((scol & 7) == 0) s_xs[((scol + TPR * i) >> 3) * 16 + srow] = p;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) {
+            const int blk = wave + WAVES * i;                // block within the phase
+#pragma unroll
+            for (int h = 0; h < GPB; ++h) {
+                const int g = blk * GPB + h;                 // group within the phase
+                const f32x4 xs = *reinterpret_cast<const f32x4*>(s_xs + g * 16 + fc * 4);
+                const uint4 x0 = *reinterpret_cast<const uint4*>(s_x + (size_t)fr * XSTRIDE + ((g * 2 + 0) * 32 + fc * 8) * 2);
+                const uint4 x1 = *reinterpret_cast<const uint4*>(s_x + (size_t)fr * XSTRIDE + ((g * 2 + 1) * 32 + fc * 8) * 2);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x0), frag_of<BITS>(wq[t][kp * KBW + i], 2 * h + 0), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x1), frag_of<BITS>(wq[t][kp * KBW + i], 2 * h + 1), acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tot[t][j] += sc[t][kp * KBW + i][h] * acc[j] + bi[t][kp * KBW + i][h] * xs[j];
+                }
             }
         }
     }
@@ -344,15 +369,15 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
 
 template <int BITS, int WAVES, int KBW, int NT>
 constexpr size_t gemvq_lds() {
-    constexpr int K = KBW * WAVES * (BITS == 4 ? 128 : 64);
+    constexpr int K = KBW * WAVES * (BITS == 4 ? 128 : 64);                  // columns per phase
     return (size_t)16 * (2 * K + 16) + (size_t)(K / 64) * 16 * 4 + (size_t)WAVES * NT * 1024;
 }
 
-template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI>
+template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI, int KPH = 1>
 static bool gemvq_go(const DecGemvQArgs& a2, hipStream_t s) {
     constexpr size_t lds = gemvq_lds<BITS, WAVES, KBW, NT>();
     static_assert(lds <= 156 * 1024, "LDS image too large");
-    auto kern = decode_gemvq_kernel<BITS, SBF32, NT, WAVES, KBW, PRO, EPI>;
+    auto kern = decode_gemvq_kernel<BITS, SBF32, NT, WAVES, KBW, PRO, EPI, KPH>;
     static bool attr_set = false;
     if (!attr_set) {
         QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -371,6 +396,9 @@ static bool gemvq_k(const DecGemvQArgs& a2, hipStream_t s) {
         case 2048: return gemvq_go<BITS, SBF32, NT, 8, 2 * M, PRO, EPI>(a2, s);
         case 3072:
             if constexpr (PRO == QPRO_COPY) return gemvq_go<BITS, SBF32, NT, 8, 3 * M, PRO, EPI>(a2, s);
+            else return false;
+        case 6144:            // 1.7B down-projection: two phases of 3072 columns
+            if constexpr (PRO == QPRO_COPY) return tuning().gemv_wide ? gemvq_go<BITS, SBF32, NT, 8, 3 * M, PRO, EPI, 2>(a2, s) : false;
             else return false;
         default: return false;
     }

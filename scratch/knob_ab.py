@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--bits", type=int, default=16, choices=[16, 8, 4], help="16 = bf16 decoder, 4 / 8 = MLX-quantised, packed")
     ap.add_argument("--preset", default="0.6B", choices=["0.6B", "1.7B"])
+    ap.add_argument("--allow-token-drift", action="store_true", help="variants that are not bit-identical by construction (another summation order)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     variants = []
@@ -62,7 +63,7 @@ def main():
             toks, lens = m.batch_tokens()
             if ref_tokens is None:
                 ref_tokens = toks.copy()
-            assert np.array_equal(toks, ref_tokens), f"variant {name} changed the tokens"
+            assert a.allow_token_drift or np.array_equal(toks, ref_tokens), f"variant {name} changed the tokens"
             ms, steps = m.batch_timings()
             if r > 0:
                 res[name].append(ms)

@@ -106,6 +106,42 @@ def test_full_width_tuned_kernels(full_sd, bits, sb_f32):
         eng.close()
 
 
+@pytest.mark.parametrize("bits", [4, 8], ids=["w4", "w8"])
+def test_1p7b_width_down_projection_in_two_column_phases(bits):
+    """Qwen3-ASR-1.7B decoder widths (hidden 2048, inter 6144) with 2 layers: the K = 6144 down-projection does not fit one LDS
+    image of its 16 activation rows and takes the two-phase form of decode_gemvq_kernel (KPH = 2); against the quantised oracle,
+    against the generic kernel it replaced (`gemv_wide = 0`), at 1 and 18 batch rows (two row groups, the second nearly empty)."""
+    t = dataclasses.replace(C.TEXT_LARGE, layers=2)
+    sd = synth.synth_state_dict(dataclasses.replace(C.AUDIO_LARGE, layers=1), t, seed=1, init="stress")
+    qsd = synth.quantize_state_dict(sd, bits)
+    eng = gpu_util.Engine("1.7B", max_batch=18, max_audio_seconds=3, max_new_tokens=16, enc_layers=1, dec_layers=2, bits=bits)
+    try:
+        eng.load_state_dict(qsd)
+        W = decoder.Weights(qsd)
+        emb = P.bf16_round(torch.randn(40, t.hidden, generator=torch.Generator().manual_seed(4)) * 0.5)
+        with torch.no_grad():
+            toks, logits = decoder.greedy(emb, W, t, P.REFERENCE, C.TOKENS, max_tokens=6, ignore_eos=True, return_logits=True)
+        _check(eng.prefill_logits(emb.numpy()), logits[0].numpy(), 3e-2, "prompt pass")
+        got = eng.decode_forced(toks[:-1])
+        for i in range(len(toks) - 1):
+            _check(got[i], logits[i + 1].numpy(), 3e-2, f"step {i} (two-phase kernel)")
+        eng.set_tuning("gemv_wide", 0)
+        try:
+            eng.prefill_logits(emb.numpy())
+            gen = eng.decode_forced(toks[:-1])
+        finally:
+            eng.set_tuning("gemv_wide", 1)
+        for i in range(len(toks) - 1):
+            _check(gen[i], logits[i + 1].numpy(), 3e-2, f"step {i} (generic kernel)")
+            assert np.abs(got[i] - gen[i]).max() <= _ulp_tol(gen[i])
+        clips = [synth.synth_waveform(k, 0.6 + 0.07 * (k % 4)) for k in range(18)]
+        a = eng.transcribe_batch(clips, max_tokens=4, ignore_eos=True)
+        for k in (0, 15, 16, 17):
+            assert eng.transcribe_batch([clips[k]], max_tokens=4, ignore_eos=True)[0] == a[k], k
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("bits,sb_f32", [(4, False), (8, True)], ids=["w4", "w8-f32scales"])
 def test_lm_head_weight_rings_agree_bit_for_bit(full_sd, bits, sb_f32):
     """The quantised LM head streams its weights either through a four-block register ring or through a wave-private LDS
