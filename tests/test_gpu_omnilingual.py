@@ -143,6 +143,22 @@ def test_7b_width_one_layer():
         m.close()
 
 
+def test_1b_width_one_layer():
+    """Omnilingual-ASR-CTC-1B (D 1280, 20 heads x 64, FFN 5120; OmnilingualMLXConfig.swift:88-103): the one published width that is
+    not a power of two -- positional conv groups of 80 channels, 5 / 15 / 20 column tiles of 256, the generic LayerNorm form -- with
+    one transformer layer against the oracle; a ragged batch equals the single-clip calls.  (3B has the 7B widths.)"""
+    cfg = dataclasses.replace(O.VARIANTS["1B"], layers=1)
+    sd = synth.synth_omnilingual_state_dict(cfg, seed=19)
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="1B", layers=1, max_batch=3, max_audio_seconds=8)
+    try:
+        _check_logits(m, sd, cfg, _wave(9, 5.3), "1B width, 1 layer")
+        clips = [_wave(k, 0.9 + 2.3 * k) for k in range(3)]
+        out = m.transcribe_batch(clips)
+        assert [m.transcribe_batch([c])[0] for c in clips] == out
+    finally:
+        m.close()
+
+
 def test_maximum_clip_length_40s():
     """The reference's cap (40 s = 640 000 samples -> 1999 frames, OmnilingualMLXModel.swift:154-159) at the 300M widths, one
     layer: the longest attention sweep (32 key tiles, 16 query blocks per head), the largest conv row tables, and one sample
