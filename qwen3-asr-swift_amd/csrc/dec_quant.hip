@@ -423,7 +423,7 @@ static bool gemvq_epi(DecEpi epi, bool norm, const DecGemvQArgs& a2, hipStream_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// Generic kernel for shapes without a tuned instantiation (test geometries, K = 6144): one workgroup per output column,
+// Generic kernel for shapes without a tuned instantiation (test geometries; K = 6144 only with gemv_wide = 0): one workgroup per output column,
 // thread b = batch row, the factored sum on the vector unit straight from the row-major triplet.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float qdot_row(const QuantRaw& q, long row, const bf16_t* __restrict__ x) {
