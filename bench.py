@@ -102,11 +102,11 @@ def stage_roofline(B, seconds, n_dec, stage_ms, steps, bits=16):
 
 
 def kernel_source_stamp():
-    """sha256 (first 16 hex) of the decode-kernel sources: a PMC traffic file is only quoted for the kernels it was
+    """sha256 (first 16 hex) of the decode-attention kernel's sources (its own translation unit and the headers it includes): a PMC traffic file is only quoted for the kernels it was
     measured on (profiles/*_pmc_traffic.json carries the stamp of the build it was taken from)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("dec_kernels.hip", "dec_kernels.h", "dec_epilogue.h", "common.h"):
+    for f in ("dec_attention.hip", "dec_rope.h", "dec_kernels.h", "common.h"):
         h.update(open(os.path.join(ROOT, "qwen3-asr-swift_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

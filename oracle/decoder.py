@@ -108,7 +108,7 @@ class DecoderState:
 
 
 def flash_prefill_attention(qh, kh, vh, scale, off, tile=64):
-    """Restatement of the HIP prompt-pass attention (csrc/dec_kernels.hip: prefill_attention_kernel):
+    """Restatement of the HIP prompt-pass attention (csrc/dec_prefill.hip: prefill_attention_kernel):
     online softmax over key tiles of `tile`, un-normalised P rounded to bf16 before P.V, running
     sum taken over the rounded P, one division at the end.  qh [H, T, hd], kh/vh [H, ctx, hd].
     The reference's own SDPA internals (MLXFast, not in its tree) are unobservable; this is the

@@ -1,4 +1,4 @@
-// dec_epilogue.h -- epilogues of the decode-step skinny GEMMs, shared by the bf16 (dec_kernels.hip) and the MLX-quantised
+// dec_epilogue.h -- epilogues of the decode-step skinny GEMMs, shared by the bf16 (dec_gemv.hip, dec_gemv_wide.hip) and the MLX-quantised
 // (dec_quant.hip) kernels.  A lane holds, per (row tile t, batch tile b), four consecutive outputs n of one batch row.
 #pragma once
 #include "dec_kernels.h"

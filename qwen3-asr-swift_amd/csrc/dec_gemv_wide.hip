@@ -1,7 +1,7 @@
 // dec_gemv_wide.hip -- decode-step skinny GEMM for K too wide for one LDS image of the 16 activation rows (the 1.7B preset's
 // down-projection: K = 6144, 16 rows x 12 KiB = 192 KiB against 160 KiB of LDS).
 //
-// Same form as decode_gemv2_kernel (dec_kernels.hip): one workgroup of 8 waves per (16-column weight tile, 16 batch rows), every
+// Same form as decode_gemv2_kernel (dec_gemv.hip): one workgroup of 8 waves per (16-column weight tile, 16 batch rows), every
 // wave first puts ALL its weight fragments in flight (fragment-major image, 1 KiB per wave instruction), MFMA operands A = weights
 // from registers, B = activation rows from a padded LDS image, fixed-order cross-wave reduction, epilogue on wave 0.  The difference:
 // the activation rows are staged in KPH column phases of K / KPH columns through the same image (barrier, MFMAs of that phase's
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512) void decode_gemv_wide_kernel(DecGemvArgs a) {
     const bf16_t* xp = a.X + (long)(srow < a.B ? srow : 0) * K + scol * 8;
     uint4 xr[KPH][XI];
     // activation rows of phase 0 first and waited for (they are a fabric read behind the kernel boundary; the weight stream queued
-    // ahead of them delays them: dec_kernels.hip, decode_gemv2_kernel), then every weight fragment, then the later phases' rows
+    // ahead of them delays them: dec_gemv.hip, decode_gemv2_kernel), then every weight fragment, then the later phases' rows
 #pragma unroll
     for (int i = 0; i < XI; ++i) xr[0][i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
     if (srow >= a.B) {

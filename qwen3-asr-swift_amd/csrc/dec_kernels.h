@@ -36,7 +36,7 @@ struct KVLayout {          // one layer's cache, bf16, per (slot, kv head) a blo
                            // writes it, v_transpose reads it back in the same layer); decode never touches it
     int max_ctx, kv_heads, hd;
     // the values the decode sweep reads: MFMA-fragment order [key/32][d/16][lane 64][8], see vfrag_index() in
-    // dec_kernels.hip; written by v_transpose (prompt) and decode_attention (append)
+    // dec_attention.hip; written by v_transpose (prompt) and decode_attention (append)
     bf16_t* vf = nullptr;
     __host__ __device__ long off(int slot, int kvh, int pos) const {
         return (((long)slot * kv_heads + kvh) * max_ctx + pos) * hd;

@@ -177,7 +177,7 @@ void gather_rows_q_launch(const QuantRaw& embed, const int* row_idx, bf16_t* dst
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tuned decode-step kernel.  Same skeleton as decode_gemv2_kernel (dec_kernels.hip): a workgroup = one 16-row weight tile
+// Tuned decode-step kernel.  Same skeleton as decode_gemv2_kernel (dec_gemv.hip): a workgroup = one 16-row weight tile
 // group (NT tiles) x 16 batch rows; activation loads first, then ALL packed weights of the wave (a whole matrix is
 // 1 - 4 MB at 4 bit: in flight at once), activations staged through LDS with the RMSNorm applied on the way, k-blocks
 // interleaved over the waves, fixed-order cross-wave reduction.  Differences:
