@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                  const bf16_t* __restrict__ vt, int vt_stride,
                                                                  const int* __restrict__ cu,
                                                                  const int* __restrict__ slot_of_clip, int heads,
-                                                                 bf16_t* __restrict__ out, float scale) {
+                                                                 bf16_t* __restrict__ out, float scale, int heavy_first) {
     constexpr int KT = 64, KS = HD / 32, DT = HD / 16, KCH = HD / 8, REP = 2;
     constexpr int TILE_BYTES = KT * HD * 2;                       // K tile and V^T tile have the same size
     constexpr int K_RPI = 64 / KCH, K_IPW = KT / K_RPI / 4;       // rows per wave instruction, instructions per wave
@@ -484,7 +484,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     __shared__ __attribute__((aligned(16))) char smem[2][2][TILE_BYTES];   // [buffer][K | V^T]
-    const int clip = blockIdx.z, kvh = blockIdx.y, q0 = blockIdx.x * 64;
+    // causal: query tile i sweeps i + 1 key tiles.  heavy_first: grid (kv head, clip, query tile) with the LAST query tile dispatched
+    // first -- the long workgroups start at once and the short ones fill the tail (the other order interleaves 1..7-tile workgroups and
+    // ends on whichever long one started last); a kv head then also stays on one XCD (workgroup id % 8), with its K / V^T tiles in that L2
+    const int clip = heavy_first ? blockIdx.y : blockIdx.z, kvh = heavy_first ? blockIdx.x : blockIdx.y;
+    const int q0 = (heavy_first ? gridDim.z - 1 - blockIdx.z : blockIdx.x) * 64;
     const int row0 = cu[clip], T = cu[clip + 1] - row0;
     if (q0 >= T) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
@@ -652,11 +656,12 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
     const int form = tuning().pa_form;      // A/B knob: 2 = transposed-score form
     const float scale = 1.0f / sqrtf((float)cache.hd);
     if (form >= 2 && heads == 2 * cache.kv_heads && (cache.hd == 128 || cache.hd == 32)) {
-        const dim3 grid(cdiv(max_len, 64), cache.kv_heads, n_clips);
+        const int hf = tuning().pa_order != 0 && cache.kv_heads == 8 ? 1 : 0;     // A/B knob; the XCD argument holds for 8 kv heads
+        const dim3 grid = hf ? dim3(cache.kv_heads, n_clips, cdiv(max_len, 64)) : dim3(cdiv(max_len, 64), cache.kv_heads, n_clips);
         if (cache.hd == 128)
-            hipLaunchKernelGGL((prefill_attention2_kernel<128>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
+            hipLaunchKernelGGL((prefill_attention2_kernel<128>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
         else
-            hipLaunchKernelGGL((prefill_attention2_kernel<32>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale);
+            hipLaunchKernelGGL((prefill_attention2_kernel<32>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
         return;
     }
     if (cache.hd == 128 && mt == 2)

@@ -12,7 +12,7 @@ struct Entry { const char* key; int Tuning::*field; };
 const Entry kEntries[] = {
     {"gemv_splitb", &Tuning::gemv_splitb}, {"gemv_w1024", &Tuning::gemv_w1024}, {"gemv_wide", &Tuning::gemv_wide},
     {"da_waves", &Tuning::da_waves}, {"da_spec", &Tuning::da_spec},
-    {"pa_form", &Tuning::pa_form}, {"pa_mt", &Tuning::pa_mt}, {"qknr_wide", &Tuning::qknr_wide},
+    {"pa_form", &Tuning::pa_form}, {"pa_mt", &Tuning::pa_mt}, {"pa_order", &Tuning::pa_order}, {"qknr_wide", &Tuning::qknr_wide},
     {"enc_attn", &Tuning::enc_attn}, {"mha_form", &Tuning::mha_form}, {"gemm_p8", &Tuning::gemm_p8}, {"gemm_nbuf", &Tuning::gemm_nbuf},
     {"lmh_q_ring", &Tuning::lmh_q_ring}, {"lmh_grid", &Tuning::lmh_grid}, {"lmh_diag", &Tuning::lmh_diag},
     {"decode_split", &Tuning::decode_split}, {"decode_gran", &Tuning::decode_gran}, {"graph_steps", &Tuning::graph_steps}, {"use_graph", &Tuning::use_graph}, {"device_sampler", &Tuning::device_sampler},

@@ -16,6 +16,7 @@ struct Tuning {
     int da_spec = 0;         // 1: first K/V loads issued before ctx_len is known
     int pa_form = 2;         // prompt attention: 2 transposed-score form | 1 first form (a third, 32x32x16 form was measured and dropped:
                              // profiles/r02_ab_prompt_attention_form3.txt)
+    int pa_order = 1;        // prompt attention workgroup order: 1 longest query tiles first, kv head = XCD | 0 query tile fastest
     int pa_mt = 1;           // row tiles per wave of the first form
     int qknr_wide = 1;       // q/k norm + RoPE of the prompt pass: 16-byte accesses
     int enc_attn = 1;        // Qwen3 audio-encoder window attention at head_dim 64: 1 the wav2vec2 path's 32x32x16 kernel | 0 16-row kernel
