@@ -117,7 +117,10 @@ struct DecGemv2Args {
     int rows_per_group;
 };
 
-template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI>
+// PARTIAL (host: fewer than 16 batch rows, norm prologue): batch rows past the end get a zero image without the ~250 vector instructions of
+// the normalisation, so the waves that own live rows have the SIMDs to themselves (1 / 8 clips: decode -1.5 %); as a run-time branch in
+// the one kernel it cost the full-tile launches 3 % (profiles/r02_ab_gemv_skip_dead_rows.txt), hence a separate instantiation
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     DecGemvArgs a = a2.g;
@@ -207,7 +210,10 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
         }
         // ---- 2. activation rows -> LDS (the weight loads stay in flight) -------------------------------
         char* xrow = s_x + (size_t)srow * XSTRIDE + scol * 16;
-        if constexpr (PRO == DEC_PRO_RMSNORM) {
+        if (PARTIAL && PRO == DEC_PRO_RMSNORM && ph * RPP + srow >= a.B) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = make_uint4(0, 0, 0, 0);
+        } else if constexpr (PRO == DEC_PRO_RMSNORM) {
             float ss = 0.0f;
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
@@ -346,13 +352,13 @@ constexpr size_t gemv2_lds() {
     return (size_t)(ALLROWS ? 16 * NB : 16) * (2 * (KSW * WAVES * 32) + 16) + (size_t)(WAVES - 1) * NT * NB * 1024;
 }
 
-template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI>
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false>
 static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
     constexpr size_t lds = gemv2_lds<NT, NB, WAVES, KSW, ALLROWS>();
     if constexpr (lds > 156 * 1024) {
         return false;
     } else {
-        auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI>;
+        auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL>;
         static bool attr_set = false;
         if (!attr_set) {
             QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -381,7 +387,11 @@ static bool gemv2_nb(const DecGemv2Args& a2, hipStream_t s) {
     // all batch rows resident in LDS when they fit (LDS and staging registers), else 16 rows per phase
     constexpr bool fit2 = gemv2_lds<NT, 2, WAVES, KSW, true>() <= 150 * 1024 && NT * KSW * 4 + 2 * KSW * 4 <= 170;
     switch (nb) {
-        case 1: return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI>(a2, s);
+        case 1:
+            if constexpr (PRO == DEC_PRO_RMSNORM && EPI != DEC_EPI_LOGITS) {
+                if (a2.g.B < 16 && tuning().gemv_partial) return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, true>(a2, s);
+            }
+            return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI>(a2, s);
         case 2:
             if constexpr (fit2) return gemv2_go<NT, 2, WAVES, KSW, true, PRO, EPI>(a2, s);
             else return gemv2_go<NT, 2, WAVES, KSW, false, PRO, EPI>(a2, s);

@@ -10,7 +10,7 @@ namespace qasr {
 namespace {
 struct Entry { const char* key; int Tuning::*field; };
 const Entry kEntries[] = {
-    {"gemv_splitb", &Tuning::gemv_splitb}, {"gemv_w1024", &Tuning::gemv_w1024}, {"gemv_wide", &Tuning::gemv_wide},
+    {"gemv_splitb", &Tuning::gemv_splitb}, {"gemv_w1024", &Tuning::gemv_w1024}, {"gemv_wide", &Tuning::gemv_wide}, {"gemv_partial", &Tuning::gemv_partial},
     {"da_waves", &Tuning::da_waves}, {"da_spec", &Tuning::da_spec},
     {"pa_form", &Tuning::pa_form}, {"pa_mt", &Tuning::pa_mt}, {"pa_order", &Tuning::pa_order}, {"qknr_wide", &Tuning::qknr_wide},
     {"enc_attn", &Tuning::enc_attn}, {"mha_form", &Tuning::mha_form}, {"gemm_p8", &Tuning::gemm_p8}, {"gemm_nbuf", &Tuning::gemm_nbuf},

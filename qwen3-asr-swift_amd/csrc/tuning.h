@@ -11,6 +11,7 @@ namespace qasr {
 struct Tuning {
     int gemv_splitb = 2;     // decode GEMV batch row groups on gridDim.y: 0 none | 1 residual GEMVs | 2 all
     int gemv_w1024 = 8;      // waves per workgroup for K = 1024 (8 x 4 k-steps | 4 x 8)
+    int gemv_partial = 1;    // fewer than 16 batch rows: norm GEMVs skip the normalisation of rows past the end (own instantiation) | 0 off
     int gemv_wide = 1;       // K = 6144 (1.7B down-projection): 1 two-phase LDS image, weights in registers (dec_gemv_wide.hip) | 0 generic kernel
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
     int da_spec = 0;         // 1: first K/V loads issued before ctx_len is known
