@@ -137,7 +137,10 @@ int qasr_finalize(qasr_engine* e);                      /* checks completeness, 
 int qasr_set_vocab(qasr_engine* e, const int32_t* ids, const char* const* tokens, size_t n);
 int qasr_is_loaded(const qasr_engine* e);
 int qasr_unload(qasr_engine* e);
-size_t qasr_memory_footprint(const qasr_engine* e);     /* parameter bytes resident in HBM */
+/* Weight bytes resident in HBM: the uploaded tensors plus everything qasr_finalize derives from them (fused q|k|v / gate|up,
+ * fragment-major decode-step images; for an MLX 4 / 8-bit checkpoint the packed decode images and ONE layer-sized bf16 scratch the
+ * prompt pass dequantises into -- no bf16 expansion of the decoder stays resident).  KV caches / workspaces are not counted. */
+size_t qasr_memory_footprint(const qasr_engine* e);
 void qasr_destroy(qasr_engine* e);
 const char* qasr_last_error(const qasr_engine* e);      /* e may be NULL: last create() failure */
 int qasr_input_sample_rate(const qasr_engine* e);       /* 16000 */

@@ -208,7 +208,9 @@ std::vector<int32_t> aligner_enforce_monotonicity(const int32_t* raw, size_t n) 
 }
 
 int aligner_find_trailing_plateau(const float* starts, size_t n, float tol, int min_size) {   // ForcedAligner.swift:196-215
-    if ((long)n <= (long)min_size) return (int)n;
+    // n == 0 or a non-positive min_size never reach the scan below (`n - 1` would wrap): "no plateau", like the reference's
+    // `guard alignedWords.count > minSize` for its only caller (minSize = 5)
+    if (n == 0 || min_size <= 0 || (long)n <= (long)min_size) return (int)n;
     size_t plateau = n;
     for (size_t i = n - 1; i >= 1; --i) {
         if (std::fabs(starts[i] - starts[i - 1]) < tol) plateau = i - 1;

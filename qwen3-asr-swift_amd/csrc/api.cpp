@@ -537,6 +537,8 @@ int qasr_ctc_transcribe(qasr_ctc_engine* e, const float* pcm, size_t n, int samp
     if (!pcm) return QASR_ERR_INVALID;
     std::vector<std::vector<int32_t>> col;
     if (int rc = ctc_run(e, &pcm, &n, 1, sample_rate, col, nullptr)) return rc;
+    // no SentencePiece vocabulary: an error, not "" for every clip (the reference cannot exist without one, OmnilingualMLXModel.swift:86-98)
+    if (!e->impl->has_pieces()) return cfail(e, QASR_ERR_NOT_LOADED, "no SentencePiece vocabulary: load tokenizer.model or call qasr_ctc_set_pieces");
     try { e->impl->result_text = e->impl->detokenize(col[0].data(), (int)col[0].size()); }
     catch (const std::exception& ex) { return cfail(e, QASR_ERR_INVALID, ex.what()); }
     *text = e->impl->result_text.c_str();
@@ -551,6 +553,7 @@ int qasr_ctc_logits(qasr_ctc_engine* e, const float* pcm, size_t n, float* logit
 
 int qasr_ctc_detokenize(qasr_ctc_engine* e, const int32_t* ids, int32_t n, char* buf, size_t cap) {
     if (!e || (!ids && n) || !buf || cap == 0 || n < 0) return -1;
+    if (!e->impl->has_pieces()) { cfail(e, QASR_ERR_NOT_LOADED, "no SentencePiece vocabulary"); return -1; }
     try {
         std::string t = e->impl->detokenize(ids, n);
         if (t.size() + 1 > cap) { cfail(e, QASR_ERR_CAPACITY, "detokenize: buffer too small"); return -1; }

@@ -35,6 +35,7 @@ public:
     // vocabulary (OmnilingualVocabulary)
     void set_pieces(const char* const* texts, const int32_t* types, size_t n);
     void load_sentencepiece(const std::string& path);
+    bool has_pieces() const { return !pieces_.empty(); }
     std::string detokenize(const int32_t* ids, int n) const;
     std::string result_text;
 

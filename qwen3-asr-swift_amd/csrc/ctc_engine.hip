@@ -24,6 +24,11 @@ int CtcEngine::num_frames(long n) {                         // Wav2Vec2Frontend.
 static long conv_len(long L, int i) { return L < kKernels[i] ? 0 : (L - kKernels[i]) / kStrides[i] + 1; }
 
 CtcEngine::CtcEngine(const qasr_ctc_config& cfg) : cfg_(cfg) {
+    // every dimension positive BEFORE any division or modulo (a zeroed / garbage config is QASR_ERR_INVALID, never SIGFPE)
+    if (cfg_.model_dim <= 0 || cfg_.layers <= 0 || cfg_.heads <= 0 || cfg_.ffn_dim <= 0 || cfg_.feature_dim <= 0 || cfg_.pos_kernel <= 0 ||
+        cfg_.pos_groups <= 0 || cfg_.vocab <= 0 || cfg_.max_batch <= 0 || cfg_.max_audio_seconds <= 0 || cfg_.max_audio_seconds > 40 ||
+        !(cfg_.ln_eps > 0.0f))
+        throw std::invalid_argument("omnilingual config: every dimension and capacity must be positive (max_audio_seconds <= 40, the reference's cap)");
     if (cfg_.model_dim % cfg_.heads || cfg_.model_dim % cfg_.pos_groups || (cfg_.model_dim / cfg_.pos_groups) % 8 ||
         cfg_.feature_dim % 8 || cfg_.vocab % 4 || cfg_.model_dim % 8 || cfg_.ffn_dim % 8)
         throw std::invalid_argument("omnilingual config: widths must be multiples of 8 (vocab of 4), heads / groups must divide model_dim");
@@ -50,7 +55,7 @@ CtcEngine::CtcEngine(const qasr_ctc_config& cfg) : cfg_(cfg) {
     d_convf_.alloc((size_t)cap_conv_rows_ * C * sizeof(float));
     d_rows_.alloc((size_t)cap_conv_rows_ * sizeof(long));
     d_x_.alloc((size_t)cap_frames_ * D * sizeof(float));
-    d_y_.alloc((size_t)cap_frames_ * D * sizeof(float));
+    d_y_.alloc((size_t)cap_frames_ * std::max(D, C) * sizeof(float));   // also holds the last extractor layer's [frames][C] f32 output
     d_h_.alloc((size_t)cap_frames_ * std::max(D, C) * sizeof(bf16_t));
     d_qkv_.alloc((size_t)cap_frames_ * 3 * D * sizeof(bf16_t));
     d_att_.alloc((size_t)cap_frames_ * D * sizeof(bf16_t));
@@ -113,8 +118,11 @@ void CtcEngine::load_directory(const std::string& dir) {
             set_tensor(kv.first, wide.data(), QASR_DTYPE_F32, e.shape.data(), (int)e.shape.size());
         }
     }
+    // the reference refuses to load without the SentencePiece model (OmnilingualMLXModel.swift:86-92): a mis-staged directory is an
+    // error here too, not an engine that answers "" for every clip
     std::ifstream probe(dir + "/tokenizer.model", std::ios::binary);
-    if (probe.good()) load_sentencepiece(dir + "/tokenizer.model");
+    if (!probe.good()) throw std::runtime_error("tokenizer.model not found at " + dir + "/tokenizer.model");
+    load_sentencepiece(dir + "/tokenizer.model");
 }
 
 const Tensor& CtcEngine::tensor(const std::string& name) const {
@@ -224,7 +232,12 @@ void CtcEngine::finalize() {
         bf16_t* w = (bf16_t*)new_buf((size_t)D * KP * cpg * sizeof(bf16_t));
         hipLaunchKernelGGL(wn_fuse_kernel, dim3(cdiv((long)D * cpg * KP, 256)), dim3(256), 0, stream_, g, v, norm, w, D, cpg, KP);
         pos_w_ = w;
-        pos_b_ = f32_param(p + ".bias", {D});
+        if (tensors_.count(p + ".bias")) pos_b_ = f32_param(p + ".bias", {D});
+        else {   // optional in the reference (OmnilingualMLXWeightLoader.swift:80-82): the Conv1d keeps its zero-initialised bias
+            float* z = (float*)new_buf((size_t)D * sizeof(float));
+            QASR_HIP(hipMemsetAsync(z, 0, (size_t)D * sizeof(float), stream_));
+            pos_b_ = z;
+        }
     }
     layers_.clear();
     for (int l = 0; l < cfg_.layers; ++l) {

@@ -36,8 +36,10 @@ size_t quant_sb_bytes(int N, int K, int sb_f32);
 void quant_pack_launch(const QuantRaw& src, uint32_t* qp, void* sb, hipStream_t s);
 
 // out[n][k] = bf16(scale * q + bias): the weight the reference's prompt-pass kernel (qmm_t) multiplies by, and the row
-// `dequantized()` returns for the embedding lookup.  rows [r0, r0 + nrows) of src -> out rows [0, nrows), ld = K.
-void quant_dequant_rows_launch(const QuantRaw& src, int r0, int nrows, bf16_t* out, hipStream_t s);
+// `dequantized()` returns for the embedding lookup.  rows [r0, r0 + nrows) of src -> out rows [0, nrows), ld = K; with block > 0,
+// source row i lands at out row (i / block) * block_stride + block_off + i % block (gate | up interleaved in 16-row blocks).
+void quant_dequant_rows_launch(const QuantRaw& src, int r0, int nrows, bf16_t* out, hipStream_t s, int block = 0, int block_stride = 0,
+                               int block_off = 0);
 
 // x[p] = audio_src[p] >= 0 ? audio[audio_src[p]] : dequantized(embed row ids[p])      (Qwen3ASR.swift:236-244)
 void embed_splice_q_launch(const int* ids, const int* audio_src, const QuantRaw& embed, const bf16_t* audio, bf16_t* x,

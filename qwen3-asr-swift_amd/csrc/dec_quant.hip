@@ -139,16 +139,19 @@ void quant_pack_launch(const QuantRaw& src, uint32_t* qp, void* sb, hipStream_t 
                        reinterpret_cast<char*>(sb), src.N, G, src.sb_f32 ? 4 : 2);
 }
 
-__global__ void quant_dequant_rows_kernel(QuantRaw q, int r0, bf16_t* __restrict__ out) {
+// src row r0 + i -> out row (i / block) * block_stride + block_off + i % block (block = nrows, stride = 0: rows back to back)
+__global__ void quant_dequant_rows_kernel(QuantRaw q, int r0, bf16_t* __restrict__ out, int block, int block_stride, int block_off) {
     const long row = blockIdx.x;
-    uint4* dst = reinterpret_cast<uint4*>(out + row * q.K);
+    const long orow = (row / block) * block_stride + block_off + row % block;
+    uint4* dst = reinterpret_cast<uint4*>(out + orow * q.K);
     for (int c = threadIdx.x; c < q.K / 8; c += blockDim.x) dst[c] = quant_dequant_chunk(q, r0 + row, c);
 }
 
-void quant_dequant_rows_launch(const QuantRaw& src, int r0, int nrows, bf16_t* out, hipStream_t s) {
+void quant_dequant_rows_launch(const QuantRaw& src, int r0, int nrows, bf16_t* out, hipStream_t s, int block, int block_stride, int block_off) {
     if (nrows <= 0) return;
     if (src.K % 64 != 0) throw std::invalid_argument("quantised matrix: K must be a multiple of the group size 64");
-    hipLaunchKernelGGL(quant_dequant_rows_kernel, dim3(nrows), dim3(128), 0, s, src, r0, out);
+    if (block <= 0) { block = nrows; block_stride = 0; block_off = 0; }
+    hipLaunchKernelGGL(quant_dequant_rows_kernel, dim3(nrows), dim3(128), 0, s, src, r0, out, block, block_stride, block_off);
 }
 
 __global__ void embed_splice_q_kernel(const int* __restrict__ ids, const int* __restrict__ audio_src, QuantRaw q,

@@ -158,37 +158,44 @@ void Engine::finalize_decoder() {
                            rv = quant_raw(p + "self_attn.v_proj", nkv, H), ro = quant_raw(p + "self_attn.o_proj", H, nq),
                            rg = quant_raw(p + "mlp.gate_proj", I, H), ru = quant_raw(p + "mlp.up_proj", I, H),
                            rd = quant_raw(p + "mlp.down_proj", H, I);
-            const size_t esz = rq.sb_f32 ? 4 : 2;
-            auto cat3 = [&](const void* a, size_t na, const void* b, size_t nb, const void* c, size_t nc) {
-                char* d = (char*)new_buf(na + nb + nc);
-                QASR_HIP(hipMemcpyAsync(d, a, na, hipMemcpyDeviceToDevice, stream_));
-                QASR_HIP(hipMemcpyAsync(d + na, b, nb, hipMemcpyDeviceToDevice, stream_));
-                QASR_HIP(hipMemcpyAsync(d + na + nb, c, nc, hipMemcpyDeviceToDevice, stream_));
-                return (void*)d;
+            L.rq = rq; L.rk = rk; L.rv = rv; L.ro = ro; L.rg = rg; L.ru = ru; L.rd = rd;
+            // q|k|v rows concatenated and gate|up interleaved triplet by triplet (temporaries: only the decode-step images built from
+            // them stay resident, unless a shape has no tuned image and the generic kernel needs the fused triplet itself)
+            std::vector<std::unique_ptr<DevBuf>> tmp;
+            auto tmp_buf = [&](size_t bytes) {
+                tmp.push_back(std::make_unique<DevBuf>());
+                tmp.back()->alloc(bytes);
+                return tmp.back()->p;
             };
-            QuantRaw rqkv = rq;
-            rqkv.N = nq + 2 * nkv;
-            const size_t wrow = (size_t)H * bits / 8, srow = (size_t)(H / 64) * esz;
-            rqkv.wq = (const uint32_t*)cat3(rq.wq, nq * wrow, rk.wq, nkv * wrow, rv.wq, nkv * wrow);
-            rqkv.scales = cat3(rq.scales, nq * srow, rk.scales, nkv * srow, rv.scales, nkv * srow);
-            rqkv.biases = cat3(rq.biases, nq * srow, rk.biases, nkv * srow, rv.biases, nkv * srow);
-            QuantRaw rgu = rg;
-            rgu.N = 2 * I;
-            auto inter2 = [&](const void* a, const void* b, size_t row_bytes) {
-                char* d = (char*)new_buf((size_t)2 * I * row_bytes);
-                hipLaunchKernelGGL(interleave_rows_bytes_kernel, dim3(2 * I), dim3(128), 0, stream_, (const char*)a, (const char*)b, d, (int)row_bytes);
-                return (void*)d;
-            };
-            rgu.wq = (const uint32_t*)inter2(rg.wq, ru.wq, wrow);
-            rgu.scales = inter2(rg.scales, ru.scales, srow);
-            rgu.biases = inter2(rg.biases, ru.biases, srow);
-            auto deq = [&](const QuantRaw& r) {
-                bf16_t* d = (bf16_t*)new_buf((size_t)r.N * r.K * sizeof(bf16_t));
-                quant_dequant_rows_launch(r, 0, r.N, d, stream_);
-                return (const bf16_t*)d;
-            };
-            L.wqkv = deq(rqkv); L.wo = deq(ro); L.wgu = deq(rgu); L.wdown = deq(rd);
-            if (!aligner) { L.qkv_q = quant_image(rqkv); L.o_q = quant_image(ro); L.gu_q = quant_image(rgu); L.down_q = quant_image(rd); }
+            if (!aligner) {
+                const size_t esz = rq.sb_f32 ? 4 : 2;
+                auto cat3 = [&](const void* a, size_t na, const void* b, size_t nb, const void* c, size_t nc) {
+                    char* d = (char*)tmp_buf(na + nb + nc);
+                    QASR_HIP(hipMemcpyAsync(d, a, na, hipMemcpyDeviceToDevice, stream_));
+                    QASR_HIP(hipMemcpyAsync(d + na, b, nb, hipMemcpyDeviceToDevice, stream_));
+                    QASR_HIP(hipMemcpyAsync(d + na + nb, c, nc, hipMemcpyDeviceToDevice, stream_));
+                    return (void*)d;
+                };
+                QuantRaw rqkv = rq;
+                rqkv.N = nq + 2 * nkv;
+                const size_t wrow = (size_t)H * bits / 8, srow = (size_t)(H / 64) * esz;
+                rqkv.wq = (const uint32_t*)cat3(rq.wq, nq * wrow, rk.wq, nkv * wrow, rv.wq, nkv * wrow);
+                rqkv.scales = cat3(rq.scales, nq * srow, rk.scales, nkv * srow, rv.scales, nkv * srow);
+                rqkv.biases = cat3(rq.biases, nq * srow, rk.biases, nkv * srow, rv.biases, nkv * srow);
+                QuantRaw rgu = rg;
+                rgu.N = 2 * I;
+                auto inter2 = [&](const void* a, const void* b, size_t row_bytes) {
+                    char* d = (char*)tmp_buf((size_t)2 * I * row_bytes);
+                    hipLaunchKernelGGL(interleave_rows_bytes_kernel, dim3(2 * I), dim3(128), 0, stream_, (const char*)a, (const char*)b, d, (int)row_bytes);
+                    return (void*)d;
+                };
+                rgu.wq = (const uint32_t*)inter2(rg.wq, ru.wq, wrow);
+                rgu.scales = inter2(rg.scales, ru.scales, srow);
+                rgu.biases = inter2(rg.biases, ru.biases, srow);
+                L.qkv_q = quant_image(rqkv); L.o_q = quant_image(ro); L.gu_q = quant_image(rgu); L.down_q = quant_image(rd);
+                if (!L.qkv_q.qp || !L.gu_q.qp) for (auto& b : tmp) fused_.push_back(std::move(b));   // generic kernel reads img.raw
+                else QASR_HIP(hipStreamSynchronize(stream_));                                           // images built: drop the temporaries
+            }
             decw_.layers.push_back(L);
             continue;
         }
@@ -217,6 +224,7 @@ void Engine::finalize_decoder() {
         L.wdown_p = aligner ? nullptr : packed_copy(L.wdown, H, I);
         decw_.layers.push_back(L);
     }
+    if (decw_.quant) d_wscratch_.alloc(((size_t)(nq + 2 * nkv) * H + (size_t)H * nq + (size_t)2 * I * H + (size_t)H * I) * sizeof(bf16_t));
     // capacity: prompt = 16 fixed ids + audio tokens + context/language extras (Qwen3ASR.swift:199-233)
     const int max_audio_tok = num_audio_tokens(mel_num_frames(max_samples_));
     max_prompt_ = 16 + max_audio_tok + cfg_.max_prompt_extra;
@@ -415,6 +423,24 @@ void Engine::run_lm_head(bool want_logits, int r0, int nr, hipStream_t s) {
                    d_dh_.as<bf16_t>() + (size_t)r0 * H, s);
 }
 
+Engine::PromptW Engine::prompt_weights(int l, hipStream_t s) {
+    const DecLayerW& L = decw_.layers[l];
+    if (!decw_.quant) return {L.wqkv, L.wo, L.wgu, L.wdown};
+    const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nkv = cfg_.kv_heads * hd, I = cfg_.inter;
+    bf16_t* wqkv = d_wscratch_.as<bf16_t>();
+    bf16_t* wo = wqkv + (size_t)(nq + 2 * nkv) * H;
+    bf16_t* wgu = wo + (size_t)H * nq;
+    bf16_t* wdown = wgu + (size_t)2 * I * H;
+    quant_dequant_rows_launch(L.rq, 0, nq, wqkv, s);
+    quant_dequant_rows_launch(L.rk, 0, nkv, wqkv + (size_t)nq * H, s);
+    quant_dequant_rows_launch(L.rv, 0, nkv, wqkv + (size_t)(nq + nkv) * H, s);
+    quant_dequant_rows_launch(L.ro, 0, H, wo, s);
+    quant_dequant_rows_launch(L.rg, 0, I, wgu, s, 16, 32, 0);       // gate | up in 32-row blocks: 16 gate rows + the 16 matching up rows
+    quant_dequant_rows_launch(L.ru, 0, I, wgu, s, 16, 32, 16);
+    quant_dequant_rows_launch(L.rd, 0, H, wdown, s);
+    return {wqkv, wo, wgu, wdown};
+}
+
 void Engine::run_prefill(bool want_logits) {
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
     hipStream_t s = stream_;
@@ -428,17 +454,18 @@ void Engine::run_prefill(bool want_logits) {
         const bool aligner = cfg_.classify_num > 0;
         KVLayout kv{kcache_[aligner ? 0 : l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd,
                     aligner ? nullptr : vfcache_[l]->as<bf16_t>()};
+        const PromptW W = prompt_weights(l, s);
         rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
-        gemm_nt(ADense{h, H, P, H}, L.wqkv, H, P, nh * hd, H, EpiBiasActBf16<0>{qkv, (long)nh * hd, nullptr}, s);
+        gemm_nt(ADense{h, H, P, H}, W.wqkv, H, P, nh * hd, H, EpiBiasActBf16<0>{qkv, (long)nh * hd, nullptr}, s);
         qk_norm_rope_launch(qkv, d_p_slot_, d_p_pos_, P, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
                             d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), qr, kv, d_vt_.as<bf16_t>(), vt_stride_,
                             d_p_cu_, d_p_slotclip_, batch_, max_len_, s);
         prefill_attention_launch(qr, kv, d_vt_.as<bf16_t>(), vt_stride_, d_p_cu_, d_p_slotclip_, batch_, max_len_,
                                  cfg_.heads, at, s);
-        gemm_nt(ADense{at, nq, P, nq}, L.wo, nq, P, H, nq, EpiResidBf16{x, H}, s);
+        gemm_nt(ADense{at, nq, P, nq}, W.wo, nq, P, H, nq, EpiResidBf16{x, H}, s);
         rmsnorm_rows_launch(x, L.ln2, h, P, H, cfg_.rms_eps, s);
-        gemm_nt_swiglu(ADense{h, H, P, H}, L.wgu, H, P, 2 * I, H, EpiBiasActBf16<0>{act, I, nullptr}, s);
-        gemm_nt(ADense{act, I, P, I}, L.wdown, I, P, H, I, EpiResidBf16{x, H}, s);
+        gemm_nt_swiglu(ADense{h, H, P, H}, W.wgu, H, P, 2 * I, H, EpiBiasActBf16<0>{act, I, nullptr}, s);
+        gemm_nt(ADense{act, I, P, I}, W.wdown, I, P, H, I, EpiResidBf16{x, H}, s);
     }
     if (cfg_.classify_num > 0) { QASR_HIP(hipGetLastError()); return; }      // aligner: the caller reads d_px_ rows
     // last position of every clip -> decode rows (Qwen3ASR.swift:254-256)
@@ -530,6 +557,14 @@ GreedyState Engine::greedy_rows(int r0) const {
     return g;
 }
 
+// The one dispatch of a decode-step linear (run_decode_step and kernel_probe both go through it, so the probe times what ships).
+// float checkpoint: fragment-major bf16 images; quantised checkpoint: packed 4 / 8-bit images (dec_quant.h)
+void Engine::decode_gemv(DecEpi epi, const DecGemvArgs& a, const QuantImg& qi, const bf16_t* norm_w, bf16_t* h, hipStream_t s) {
+    if (decw_.quant) decode_gemv_q_launch(epi, a, qi, norm_w, cfg_.rms_eps, h, s);
+    else if (!norm_w && tuning().gemv_wide && decode_gemv_wide_supported(epi, a)) decode_gemv_wide_launch(epi, a, s);   // K = 6144 (1.7B)
+    else decode_gemv_fused_launch(epi, a, norm_w, norm_w ? cfg_.rms_eps : 0.f, norm_w ? h : nullptr, s);
+}
+
 // One decode step for batch rows [r0, r0 + nr) on stream s.  Rows are independent, so a step can be
 // issued as several row groups on parallel graph branches (see decode_loop).
 void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s, bool with_head) {
@@ -549,12 +584,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         unsigned long long* dbg = (stamp_buf_ && l == stamp_layer_) ? stamp_buf_ : nullptr;
         const size_t dbg_stride = (size_t)512 * 16 * 8;
         DecGemvArgs a{};
-        // float checkpoint: fragment-major bf16 images; quantised checkpoint: packed 4 / 8-bit images (dec_quant.h)
-        auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) {
-            if (decw_.quant) decode_gemv_q_launch(epi, a, qi, norm_w, cfg_.rms_eps, h, s);
-            else if (!norm_w && tuning().gemv_wide && decode_gemv_wide_supported(epi, a)) decode_gemv_wide_launch(epi, a, s);   // K = 6144 (1.7B)
-            else decode_gemv_fused_launch(epi, a, norm_w, norm_w ? cfg_.rms_eps : 0.f, norm_w ? h : nullptr, s);
-        };
+        auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) { decode_gemv(epi, a, qi, norm_w, h, s); };
         a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
         decode_gemv_set_debug(dbg);
         gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
@@ -856,13 +886,11 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     QASR_HIP(hipMemcpy(ctx.data(), gstate_.ctx_len, batch_ * sizeof(int), hipMemcpyDeviceToHost));
     // same launch shape as the captured step: one row group of the batch (see issue_decode_step)
     const int rows = decode_group_rows();
+    const PromptW probe_w = (which == 3 || which == 4) ? prompt_weights(0, s) : PromptW{};
     auto body = [&]() {
         DecGemvArgs a{};
         a.B = rows;
-        auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) {
-            if (decw_.quant) decode_gemv_q_launch(epi, a, qi, norm_w, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
-            else decode_gemv_fused_launch(epi, a, norm_w, norm_w ? cfg_.rms_eps : 0.f, norm_w ? d_dh_.as<bf16_t>() : nullptr, s);
-        };
+        auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) { decode_gemv(epi, a, qi, norm_w, d_dh_.as<bf16_t>(), s); };
         if (which == 0) {
             // the same four launches as run_decode_step (residual epilogues write a scratch row block)
             a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
@@ -878,10 +906,10 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn,
                                     L.kn, cfg_.rms_eps, rr.cos_rows, rr.sin_rows, kv, d_dattn_.as<bf16_t>(), s);
         } else if (which == 3) {      // prompt-pass QKV GEMM shape (M = packed prompt rows, N = 4096, K = 1024)
-            gemm_nt(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, L.wqkv, H, n_pos_, nh * hd, H,
+            gemm_nt(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, probe_w.wqkv, H, n_pos_, nh * hd, H,
                     EpiBiasActBf16<0>{d_pqkv_.as<bf16_t>(), (long)nh * hd, nullptr}, s);
         } else if (which == 4) {      // prompt-pass gate/up GEMM with the SwiGLU epilogue
-            gemm_nt_swiglu(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, L.wgu, H, n_pos_, 2 * I, H,
+            gemm_nt_swiglu(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, probe_w.wgu, H, n_pos_, 2 * I, H,
                            EpiBiasActBf16<0>{d_pact_.as<bf16_t>(), I, nullptr}, s);
         } else {
             run_lm_head(false, 0, batch_, s);
@@ -898,7 +926,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         DecGemvArgs a{};
         a.B = rows; a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
         for (int i = 0; i < reps; ++i) {
-            decode_gemv_fused_launch(DEC_EPI_BF16, a, L.ln1, cfg_.rms_eps, d_dh_.as<bf16_t>(), s);
+            decode_gemv(DEC_EPI_BF16, a, L.qkv_q, L.ln1, d_dh_.as<bf16_t>(), s);
             QASR_HIP(hipEventRecord(ev[2 * i], s));
             body();
             QASR_HIP(hipEventRecord(ev[2 * i + 1], s));
@@ -971,7 +999,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             }
         }
     }
-    if (which == 0 && tuning().gemv_stamps) {
+    if (which == 0 && tuning().gemv_stamps && !decw_.quant) {   // stamps live in the bf16 kernels only
         DevBuf d;
         const size_t n = (size_t)512 * 16 * 8;
         d.alloc(n * sizeof(unsigned long long));

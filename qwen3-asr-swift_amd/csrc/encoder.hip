@@ -305,20 +305,15 @@ void Engine::gemm_probe(const uint16_t* A, const uint16_t* W, const float* bias,
     QASR_HIP(hipMemcpyAsync(dW.p, W, (size_t)N * K * 2, hipMemcpyHostToDevice, s));
     if (bias) QASR_HIP(hipMemcpyAsync(dB.p, bias, (size_t)N * 4, hipMemcpyHostToDevice, s));
     else QASR_HIP(hipMemsetAsync(dB.p, 0, (size_t)N * 4, s));
-    Tuning& t = tuning();
-    const int p8 = t.gemm_p8, nbuf = t.gemm_nbuf;
-    if (form == 0) { t.gemm_p8 = 0; t.gemm_nbuf = 2; }
-    else if (form == 1) { t.gemm_p8 = 0; t.gemm_nbuf = 1; }
-    else if (form == 2) t.gemm_p8 = 2;
     hipEvent_t e0, e1;
     QASR_HIP(hipEventCreate(&e0));
     QASR_HIP(hipEventCreate(&e1));
     try {
         const ADense a{dA.as<bf16_t>(), K, M, K};
         const EpiBiasF32 epi{dO.as<float>(), N, dB.as<float>()};
-        gemm_nt(a, dW.as<bf16_t>(), K, M, N, K, epi, s);                  // warm
+        gemm_nt(a, dW.as<bf16_t>(), K, M, N, K, epi, s, form);            // warm
         QASR_HIP(hipEventRecord(e0, s));
-        for (int r = 0; r < reps; ++r) gemm_nt(a, dW.as<bf16_t>(), K, M, N, K, epi, s);
+        for (int r = 0; r < reps; ++r) gemm_nt(a, dW.as<bf16_t>(), K, M, N, K, epi, s, form);
         QASR_HIP(hipEventRecord(e1, s));
         QASR_HIP(hipMemcpyAsync(out, dO.p, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
         QASR_HIP(hipStreamSynchronize(s));
@@ -327,11 +322,9 @@ void Engine::gemm_probe(const uint16_t* A, const uint16_t* W, const float* bias,
         QASR_HIP(hipEventElapsedTime(&ms, e0, e1));
         if (avg_ms) *avg_ms = ms / (float)reps;
     } catch (...) {
-        t.gemm_p8 = p8; t.gemm_nbuf = nbuf;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         throw;
     }
-    t.gemm_p8 = p8; t.gemm_nbuf = nbuf;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 }
 

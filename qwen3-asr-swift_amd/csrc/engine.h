@@ -156,6 +156,7 @@ private:
     void plan_prefill(const qasr_options* opt, const std::vector<int>& n_audio,
                       const std::vector<std::vector<int32_t>>* aligner_tails = nullptr);
     void run_prefill(bool want_logits);
+    void decode_gemv(DecEpi epi, const DecGemvArgs& a, const QuantImg& qi, const bf16_t* norm_w, bf16_t* h, hipStream_t s);
     void run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s, bool with_head);
     void issue_decode_step(int split);
     void sample_and_finalize(int advance_ctx);
@@ -216,7 +217,14 @@ private:
         const bf16_t *ln1, *wqkv, *qn, *kn, *wo, *ln2, *wgu, *wdown;
         const bf16_t *wqkv_p, *wo_p, *wgu_p, *wdown_p;       // fragment-major copies for the decode step
         QuantImg qkv_q, o_q, gu_q, down_q;                   // quantised checkpoints: packed decode-step images instead
+        QuantRaw rq{}, rk{}, rv{}, ro{}, rg{}, ru{}, rd{};   // ... and the uploaded triplets, the prompt pass's source (prompt_weights)
     };
+    struct PromptW { const bf16_t *wqkv, *wo, *wgu, *wdown; };
+    // bf16 matrices of layer l for the prompt-pass GEMMs: the resident fused tensors of a float checkpoint; for an MLX-quantised one
+    // bf16(scale * q + bias) written into ONE reusable layer-sized scratch on stream s right before use (the reference's many-row
+    // kernel multiplies by exactly that value) -- no bf16 expansion of the decoder stays resident
+    PromptW prompt_weights(int l, hipStream_t s);
+    DevBuf d_wscratch_;
     struct DecW {
         const bf16_t *embed, *norm, *embed_p;
         const bf16_t *cls_w = nullptr, *cls_b = nullptr;       // aligner: Linear(hidden, classify_num) `lm_head.{weight,bias}`

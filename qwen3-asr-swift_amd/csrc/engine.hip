@@ -113,6 +113,7 @@ void Engine::unload() {
     kcache_.clear();
     vfcache_.clear();
     d_vrows_.release();
+    d_wscratch_.release();
     batch_ = 0;
     h_ctx0_.clear();
     forced_ctx_ = 0;
@@ -122,9 +123,14 @@ void Engine::require_batch(const char* what) const {
     if (!finalized_) throw NotLoaded(std::string(what) + ": weights not finalized (unloaded, or a tensor was replaced)");
     if (batch_ <= 0 || h_ctx0_.empty()) throw std::runtime_error(std::string(what) + ": no resident batch (call qasr_batch_begin)");
 }
+// Every weight byte resident in HBM: the uploaded tensors AND what qasr_finalize derived from them (fused q|k|v and gate|up, the
+// fragment-major decode-step images, quantised decode images, the quantised engine's one-layer prompt-pass scratch).  Caches and
+// activation workspaces are capacity, not parameters, and are not counted.
 size_t Engine::memory_footprint() const {
     size_t n = 0;
     for (auto& kv : tensors_) n += kv.second.buf.bytes;
+    for (auto& b : fused_) n += b->bytes;
+    n += d_wscratch_.bytes;
     return n;
 }
 

@@ -311,15 +311,17 @@ template <class A>
 struct gemm_p8_allowed<A, std::void_t<decltype(A::no_p8)>> { static constexpr bool value = !A::no_p8; };
 
 template <class ALoad, class Epi>
-inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
+// form: -1 = the engine's pick for this shape (tuning knobs gemm_p8 / gemm_nbuf); 0 = 128x128 double-buffered, 1 = 128x128 single LDS
+// buffer, 2 = 256x256 ping-pong -- forced by qasr_gemm_probe without touching the process-wide knob table
+inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s, int form = -1) {
     if (M <= 0 || N <= 0) return;
-    if constexpr (gemm_p8_allowed<ALoad>::value) if (gemm_use_p8(M, N)) {
+    if constexpr (gemm_p8_allowed<ALoad>::value) if (form == 2 || (form < 0 && gemm_use_p8(M, N))) {
         hipLaunchKernelGGL((gemm_nt_p8_kernel<ALoad, Epi, 0>), dim3(gemm_p8_grid(M, N)), dim3(512), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
         return;
     }
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
-    if (gemm_nbuf(grid) == 1)
+    if (form == 1 || (form != 0 && gemm_nbuf(grid) == 1))
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block());
     else

@@ -1,6 +1,7 @@
 // tuning.cpp -- knob table (tuning.h): name lookup, environment seeding.
 #include "tuning.h"
 #include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -8,16 +9,35 @@
 namespace qasr {
 
 namespace {
-struct Entry { const char* key; int Tuning::*field; };
+// allowed: the enumerated values of a knob (terminated by -1), or {lo, hi, -2} for an inclusive range.  Anything else is refused:
+// a value outside the table never reaches a kernel launch (decode_gran = 0 would divide by zero, lmh_grid <= 0 sizes empty buffers).
+struct Entry { const char* key; int Tuning::*field; int allowed[6]; bool diag_only; };
 const Entry kEntries[] = {
-    {"gemv_splitb", &Tuning::gemv_splitb}, {"gemv_w1024", &Tuning::gemv_w1024}, {"gemv_wide", &Tuning::gemv_wide}, {"gemv_partial", &Tuning::gemv_partial},
-    {"da_waves", &Tuning::da_waves}, {"da_spec", &Tuning::da_spec},
-    {"pa_form", &Tuning::pa_form}, {"pa_mt", &Tuning::pa_mt}, {"pa_order", &Tuning::pa_order}, {"qknr_wide", &Tuning::qknr_wide},
-    {"enc_attn", &Tuning::enc_attn}, {"mha_form", &Tuning::mha_form}, {"gemm_p8", &Tuning::gemm_p8}, {"gemm_nbuf", &Tuning::gemm_nbuf},
-    {"lmh_q_ring", &Tuning::lmh_q_ring}, {"lmh_grid", &Tuning::lmh_grid}, {"lmh_diag", &Tuning::lmh_diag},
-    {"decode_split", &Tuning::decode_split}, {"decode_gran", &Tuning::decode_gran}, {"graph_steps", &Tuning::graph_steps}, {"use_graph", &Tuning::use_graph}, {"device_sampler", &Tuning::device_sampler},
-    {"da_stamps", &Tuning::da_stamps}, {"gemv_stamps", &Tuning::gemv_stamps}, {"stamps_insitu", &Tuning::stamps_insitu},
+    {"gemv_splitb", &Tuning::gemv_splitb, {0, 1, 2, -1}, false}, {"gemv_w1024", &Tuning::gemv_w1024, {4, 8, -1}, false},
+    {"gemv_wide", &Tuning::gemv_wide, {0, 1, -1}, false}, {"gemv_partial", &Tuning::gemv_partial, {0, 1, -1}, false},
+    {"da_waves", &Tuning::da_waves, {8, 16, -1}, false}, {"da_spec", &Tuning::da_spec, {0, 1, -1}, false},
+    {"pa_form", &Tuning::pa_form, {1, 2, -1}, false}, {"pa_mt", &Tuning::pa_mt, {1, 2, -1}, false}, {"pa_order", &Tuning::pa_order, {0, 1, -1}, false},
+    {"qknr_wide", &Tuning::qknr_wide, {0, 1, -1}, false},
+    {"enc_attn", &Tuning::enc_attn, {0, 1, -1}, false}, {"mha_form", &Tuning::mha_form, {0, 1, 2, -1}, false},
+    {"gemm_p8", &Tuning::gemm_p8, {0, 1, 2, -1}, false}, {"gemm_nbuf", &Tuning::gemm_nbuf, {0, 1, 2, -1}, false},
+    {"lmh_q_ring", &Tuning::lmh_q_ring, {0, 1, -1}, false}, {"lmh_grid", &Tuning::lmh_grid, {1, 4096, -2}, false},
+    {"lmh_diag", &Tuning::lmh_diag, {0, 1, -1}, true},
+    {"decode_split", &Tuning::decode_split, {1, 4, -2}, false}, {"decode_gran", &Tuning::decode_gran, {16, 32, 48, 64, -1}, false},
+    {"graph_steps", &Tuning::graph_steps, {1, 2, 4, 8, -1}, false}, {"use_graph", &Tuning::use_graph, {0, 1, -1}, false},
+    {"device_sampler", &Tuning::device_sampler, {0, 1, -1}, false},
+    {"da_stamps", &Tuning::da_stamps, {0, 1, -1}, true}, {"gemv_stamps", &Tuning::gemv_stamps, {0, 1, -1}, true},
+    {"stamps_insitu", &Tuning::stamps_insitu, {0, 1, -1}, true},
 };
+
+bool value_allowed(const Entry& e, int v) {
+#ifndef QASR_DIAG_STAMPS
+    if (e.diag_only && v != 0) return false;        // timing-only / wrong-result diagnostics exist in `make DIAG=1` builds only
+#endif
+    if (e.allowed[2] == -2) return v >= e.allowed[0] && v <= e.allowed[1];
+    for (int i = 0; i < 6 && e.allowed[i] != -1; ++i)
+        if (e.allowed[i] == v) return true;
+    return false;
+}
 }  // namespace
 
 Tuning& tuning() {
@@ -26,7 +46,11 @@ Tuning& tuning() {
         for (const Entry& e : kEntries) {
             std::string name = "QASR_";
             for (const char* p = e.key; *p; ++p) name += (char)std::toupper((unsigned char)*p);
-            if (const char* s = std::getenv(name.c_str())) v.*(e.field) = std::atoi(s);
+            if (const char* s = std::getenv(name.c_str())) {
+                const int x = std::atoi(s);
+                if (value_allowed(e, x)) v.*(e.field) = x;
+                else std::fprintf(stderr, "[qasr] %s=%s is not an allowed value, keeping %d\n", name.c_str(), s, v.*(e.field));
+            }
         }
         return v;
     }();
@@ -36,6 +60,7 @@ Tuning& tuning() {
 bool tuning_set(const char* key, int value) {
     for (const Entry& e : kEntries)
         if (std::strcmp(e.key, key) == 0) {
+            if (!value_allowed(e, value)) return false;
             Tuning& t = tuning();
             if (t.*(e.field) != value) { t.*(e.field) = value; ++t.epoch; }
             return true;

@@ -38,7 +38,7 @@ struct Tuning {
 };
 
 Tuning& tuning();                                   // process-wide; first call seeds it from the environment
-bool tuning_set(const char* key, int value);        // false: unknown key
+bool tuning_set(const char* key, int value);        // false: unknown key, or a value outside the knob's enumerated / ranged set
 bool tuning_get(const char* key, int* value);
 
 }  // namespace qasr

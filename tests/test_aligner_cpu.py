@@ -83,6 +83,18 @@ def test_plateau_matches_oracle():
             assert QA.find_trailing_plateau_start(s, tol, m) == OA.find_trailing_plateau_start(s, tol, m)
 
 
+def test_plateau_degenerate_arguments():
+    """n == 0 or min_size <= 0 over the public ABI: "no plateau" (= n), never a read before the array (the scan starts at n - 1)."""
+    assert QA.find_trailing_plateau_start(np.zeros(0, np.float32), 0.1, -1) == 0
+    assert QA.find_trailing_plateau_start(np.zeros(0, np.float32), 0.1, 0) == 0
+    assert QA.find_trailing_plateau_start(np.zeros(0, np.float32), 0.1, 5) == 0
+    s = np.asarray([0.0, 0.01, 0.02, 0.03], np.float32)
+    assert QA.find_trailing_plateau_start(s, 0.1, 0) == 4 and QA.find_trailing_plateau_start(s, 0.1, -3) == 4
+    assert QA.find_trailing_plateau_start(s, 0.1, 2) == 0
+    lib = _lib.load(strict=True)
+    assert lib.qasr_find_trailing_plateau(None, 3, C.c_float(0.1), 5) < 0
+
+
 def test_aligner_presets():
     lib = _lib.load(strict=True)
     cfg = _lib.QasrConfig()

@@ -97,6 +97,14 @@ def test_tuning_knobs_roundtrip():
     assert lib.qasr_set_tuning(b"no_such_knob", 1) != 0
     assert lib.qasr_get_tuning(b"no_such_knob", C.byref(v)) != 0
     assert lib.qasr_set_tuning(None, 1) != 0
+    # values outside a knob's enumerated set / range are refused and leave the table unchanged (decode_gran = 0 would divide by zero in
+    # the step issue, lmh_grid <= 0 would size empty partial buffers); timing-only diagnostics exist in `make DIAG=1` builds only
+    for key, bad in ((b"decode_gran", 0), (b"decode_gran", 17), (b"lmh_grid", 0), (b"lmh_grid", -4), (b"graph_steps", 3), (b"gemm_nbuf", 7),
+                     (b"decode_split", 0), (b"lmh_diag", 1)):
+        before = C.c_int(-1)
+        assert lib.qasr_get_tuning(key, C.byref(before)) == 0
+        assert lib.qasr_set_tuning(key, bad) != 0, (key, bad)
+        assert lib.qasr_get_tuning(key, C.byref(v)) == 0 and v.value == before.value
 
 
 # ---- pickNextToken through the C ABI (pure CPU function; reference KATs: Qwen3DecodingOptionsTests.swift:51-235)

@@ -168,8 +168,10 @@ def test_unload_and_footprint(sd):
     m = Qwen3ASRModel.from_state_dict(sd, preset="tiny", max_audio_seconds=2, max_new_tokens=8)
     try:
         assert m.is_loaded
-        want = sum(t.numel() * 2 for t in sd.values())
-        assert m.memory_footprint == want
+        # the uploaded tensors (bf16) + what finalize derives from them (fused q|k|v / gate|up, fragment-major decode images): between one
+        # and three times the checkpoint, and what the device actually gave up for weights is at least that much
+        up = sum(t.numel() * 2 for t in sd.values())
+        assert up < m.memory_footprint <= 3 * up
         m.unload()
         assert not m.is_loaded and m.memory_footprint == 0
         assert m.transcribe(synth.synth_waveform(0, 0.5), max_tokens=8).startswith("[qasr error:")
@@ -226,7 +228,14 @@ def test_safetensors_and_mlx_quantised_checkpoint(tmp_path, sd, bits, sb_dtype):
     ref = Qwen3ASRModel.from_state_dict(expect, preset="tiny", max_audio_seconds=4, max_new_tokens=16, bits=bits)
     try:
         assert m.is_loaded
-        assert m.memory_footprint == ref.memory_footprint          # packed words + scales + biases, not a bf16 expansion
+        assert m.memory_footprint == ref.memory_footprint          # same bytes whether loaded from disk or set tensor by tensor
+        # packed words + scales + biases + packed decode images + one layer of bf16 scratch: no resident bf16 expansion of the decoder
+        # (a bf16 copy of every decoder Linear alone would be 2 bytes per parameter)
+        dec_params = sum(int(np.prod(t.shape)) * (32 // bits) for k, t in expect.items() if k.startswith("model.layers.") and k.endswith(".weight") and t.dtype in (torch.int32, torch.uint32))
+        packed_bytes = sum(t.numel() * t.element_size() for t in expect.values())
+        layer_bf16 = 2 * dec_params // m.cfg.dec_layers
+        assert m.memory_footprint <= 2 * packed_bytes + layer_bf16 + 4096, (m.memory_footprint, packed_bytes, layer_bf16)
+        assert m.memory_footprint < packed_bytes + 2 * dec_params
         pcm = synth.synth_waveform(1, 2.0)
         assert m.transcribe_tokens(pcm, max_tokens=10, ignore_eos=True) == ref.transcribe_tokens(pcm, max_tokens=10, ignore_eos=True)
         assert m.detokenize([0, 1, 501, 7, 1, 0]) == "ba"

@@ -200,3 +200,35 @@ def test_quantised_differs_from_its_bf16_expansion(full_sd):
     d_f = np.linalg.norm(got - step_f) / np.linalg.norm(step_f)
     print(f"oracle exact-vs-bf16-expansion gap {gap:.2e}; device vs exact {d_q:.2e}, device vs expansion {d_f:.2e}")
     assert d_q < 3e-2
+
+
+def test_quantised_engine_device_bytes(full_sd):
+    """What the device actually gives up for a 4-bit engine (hipMemGetInfo delta around create + load + finalize, capacity of one 6 s
+    clip so that caches / workspaces are small): the reported footprint is a lower bound of it within the workspace size, and it holds
+    no bf16 expansion of the decoder -- packed tensors + packed decode images + ONE layer of bf16 scratch (the prompt pass dequantises
+    layer by layer), where bf16 copies of every decoder Linear would add 2 bytes per decoder parameter."""
+    qsd = synth.quantize_state_dict(full_sd, 4)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    eng = gpu_util.Engine("0.6B", max_batch=1, max_audio_seconds=6, max_new_tokens=16, dec_layers=3, bits=4)
+    try:
+        eng.load_state_dict(qsd)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        used = free0 - free1
+        fp = int(eng.lib.qasr_memory_footprint(eng.h))
+        uploaded = sum(t.numel() * t.element_size() for t in qsd.values())
+        dec_lin = [k for k in qsd if k.startswith("model.layers.") and k.endswith("_proj.weight")]
+        dec_params = sum(qsd[k].numel() * 8 for k in dec_lin)                       # 8 four-bit values per uint32 word
+        layer_bf16 = 2 * dec_params // 3
+        print(f"device bytes {used / 1e6:.1f} MB, footprint {fp / 1e6:.1f} MB, uploaded {uploaded / 1e6:.1f} MB, one bf16 layer {layer_bf16 / 1e6:.1f} MB")
+        assert uploaded < fp <= used + (2 << 20)                                   # allocator granularity
+        assert used - fp < 400e6                                                   # caches + activation workspaces at this capacity
+        # resident decoder weight bytes beyond the upload: decode images (~ the packed size again) + one layer of scratch, far below
+        # a bf16 copy of all three layers
+        dec_packed = sum(qsd[k].numel() * qsd[k].element_size() for k in qsd if k.startswith("model.layers.") and "_proj." in k)
+        enc_up = sum(t.numel() * t.element_size() for k, t in qsd.items() if k.startswith("audio_tower."))
+        assert fp - uploaded < enc_up + 1.25 * (dec_packed + qsd["model.embed_tokens.weight"].numel() * 4 * 1.2) + layer_bf16 + (8 << 20)
+        assert fp - uploaded < enc_up + 2 * dec_params * 0.75 + qsd["model.embed_tokens.weight"].numel() * 4 * 1.5
+    finally:
+        eng.close()
