@@ -16,6 +16,10 @@
  *   TranscribeBatchCommand (sequential loop in the reference; batched here)
  *                                                         Sources/AudioCLILib/TranscribeBatchCommand.swift:69-133
  *        -> qasr_batch_begin / qasr_batch_run / qasr_batch_tokens, qasr_transcribe_batch
+ *   Parakeet-TDT / Nemotron / Parakeet-EOU (BASELINE configs[4]; networks are opaque CoreML there): MelPreprocessor.extract,
+ *   StreamingMelPreprocessor.extract / extractRaw / extractStreaming, TDTGreedyDecoder.decode, RNNTGreedyDecoder.decode,
+ *   ParakeetVocabulary / NemotronVocabulary, StreamingSession.pushAudio   (file:line at each declaration)
+ *        -> qasr_nemo_mel_*, qasr_tdt_greedy_decode, qasr_rnnt_greedy_decode, qasr_sp_vocab_*, qasr_stream_chunker_*
  *   Stage entry points (no reference counterpart; they expose R1-R8 of SURVEY.md section 8a so
  *   each kernel can be diffed against the oracle in isolation): qasr_mel, qasr_encode,
  *   qasr_prefill_logits, qasr_decode_forced.
@@ -326,6 +330,94 @@ int qasr_ctc_timings(qasr_ctc_engine* e, float ms[4]);
  * (OmnilingualASR.swift:305-325) */
 int qasr_ctc_greedy(const float* logits, int32_t T, int32_t V, int32_t valid_frames, int32_t* out);
 int qasr_layer_normalize(const float* x, size_t n, float eps, float* out);
+
+/* ---- Parakeet-TDT / Nemotron streaming / Parakeet-EOU (BASELINE configs[4]): the restatable slice ------------------------------
+ * In the reference the FastConformer encoder, the LSTM prediction network and the joint of these models are opaque CoreML bundles
+ * (`encoder.mlmodelc`, `decoder.mlmodelc`, `joint.mlmodelc`): their arithmetic is not in its tree and is NOT rebuilt here.  What the
+ * reference does in Swift around them is: the log-mel front-end (CPU, Accelerate), the greedy transducer loops, vocabulary decode and
+ * the streaming session's chunk cutting.  Those are the entry points below; the networks are caller-supplied callbacks. */
+
+/* log-mel front-ends, batched on the device (csrc/nemo_mel.hip).  One launch serves every stream's chunk (64 concurrent streams x one
+ * 160 ms chunk replay one captured hipGraph: H2D, three kernels, D2H) where the reference makes one Accelerate call per chunk. */
+#define QASR_NEMO_MEL_TDT 0            /* MelPreprocessor.extract, Sources/ParakeetASR/MelPreprocessor.swift:52-202 (float16 values) */
+#define QASR_NEMO_MEL_EOU 1            /* StreamingMelPreprocessor.extract, Sources/ParakeetStreamingASR/StreamingMelPreprocessor.swift:62-186 */
+#define QASR_NEMO_MEL_RAW 2            /* extractRaw, Sources/NemotronStreamingASR/StreamingMelPreprocessor.swift:55-129 (= ParakeetStreamingASR :193-273) */
+#define QASR_NEMO_MEL_EOU_STREAMING 3  /* extractStreaming (running mean / std per stream), ParakeetStreamingASR/StreamingMelPreprocessor.swift:280-393 */
+typedef struct qasr_nemo_mel qasr_nemo_mel;
+/* fft_scale: 2.0 = vDSP_fft_zrip's scaling as the reference states it (NemotronStreamingASR/StreamingMelPreprocessor.swift:100); only
+ * the normalised variants depend on it (through the 2^-24 log guard), RAW divides it out. */
+int qasr_nemo_mel_create(int device, int max_streams, size_t max_samples, float fft_scale, qasr_nemo_mel** out);
+void qasr_nemo_mel_destroy(qasr_nemo_mel* m);
+const char* qasr_nemo_mel_last_error(const qasr_nemo_mel* m);      /* m may be NULL: last create() failure */
+int qasr_nemo_mel_num_frames(size_t n_samples);                     /* n / 160 + 1 */
+int qasr_nemo_mel_length(size_t n_samples);                         /* melLength = n / 160 */
+/* B clips or chunks -> out [B][128][stride] float32 (host), mel_len[b].  fit > 0: every row is cut / zero-padded to `fit` frames
+ * (StreamingSession.truncateMel / padMel, Sources/NemotronStreamingASR/StreamingSession.swift:245-274); fit <= 0: nFrames of the
+ * longest row.  A zero-length row gives zeros and mel_len 0 (the streaming variants' `guard !audio.isEmpty`); the reflect-padded
+ * variants need more than 256 samples (the Swift code indexes out of bounds below that): QASR_ERR_INVALID.  stream_ids: the running-
+ * statistics slot of each row for EOU_STREAMING (NULL = row index), ignored otherwise. */
+int qasr_nemo_mel_extract(qasr_nemo_mel* m, int variant, const float* const* pcm, const size_t* n, size_t B, const int32_t* stream_ids,
+                          float* out, size_t stride, int32_t* mel_len, int fit);
+int qasr_nemo_mel_reset_stats(qasr_nemo_mel* m, int stream);        /* resetRunningStats; stream < 0: every stream */
+/* device time of the last extract in ms (HIP events: H2D + kernels + D2H) and whether it replayed the captured graph */
+int qasr_nemo_mel_timing(const qasr_nemo_mel* m, float* ms, int* was_graph);
+
+/* transducer greedy loops (pure CPU).  The caller owns the networks and their state:
+ *   decoder_step(ctx, token)  advance the prediction network with `token` (the loops prime it with the blank id where the reference does)
+ *   joint(ctx, frame, token_logits[vocab_size + 1], duration_logits[n_durations] or NULL)  logits for encoder frame `frame` and the
+ *        current prediction-network output (the CoreML outputs are float16; pass them widened)
+ * Both return 0 on success; any other value aborts the decode with QASR_ERR_INVALID. */
+typedef struct qasr_transducer_config {
+    int32_t vocab_size;                /* 8192 Parakeet-TDT | 1024 Nemotron | 1026 Parakeet-EOU (Configuration.swift of each target) */
+    int32_t blank_id;                  /* = vocab_size */
+    int32_t eou_id;                    /* 1024 for Parakeet-EOU, -1 otherwise */
+    int32_t n_durations;               /* TDT: 5; RNNT: 0 */
+    int32_t durations[8];              /* TDT: 0 1 2 3 4 */
+    int32_t first_text_id;             /* TDT: 274 (ids below are fed to the network but not reported, TDTGreedyDecoder.swift:91-94) */
+    int32_t max_symbols;               /* RNNT: 10 symbols per encoder frame (RNNTGreedyDecoder.swift:35) */
+} qasr_transducer_config;
+typedef struct qasr_transducer_callbacks {
+    void* ctx;
+    int (*decoder_step)(void* ctx, int32_t token);
+    int (*joint)(void* ctx, int32_t frame, float* token_logits, float* duration_logits);
+} qasr_transducer_callbacks;
+/* model: "parakeet-tdt" | "nemotron-streaming" | "parakeet-eou" (or the reference's model ids containing those families' names) */
+int qasr_transducer_default_config(const char* model, qasr_transducer_config* out);
+/* TDTGreedyDecoder.decode (Sources/ParakeetASR/TDTGreedyDecoder.swift:45-143) -> number of tokens (<= cap) or -status.
+ * log_probs / confidence may be NULL. */
+int qasr_tdt_greedy_decode(const qasr_transducer_config* cfg, const qasr_transducer_callbacks* cb, int32_t encoded_length,
+                           int32_t* tokens, float* log_probs, int32_t cap, float* confidence);
+/* RNNTGreedyDecoder.decode (Sources/NemotronStreamingASR/RNNTGreedyDecoder.swift:38-90; with cfg->eou_id >= 0:
+ * Sources/ParakeetStreamingASR/RNNTGreedyDecoder.swift:58-126).  The prediction network is NOT primed here: a session primes it once
+ * (StreamingSession.swift:93-99) and its state persists across chunks. */
+int qasr_rnnt_greedy_decode(const qasr_transducer_config* cfg, const qasr_transducer_callbacks* cb, int32_t encoded_length,
+                            int32_t frame_offset, int32_t* tokens, float* log_probs, int32_t cap, int32_t* eou_detected);
+float qasr_log_softmax_at(const float* logits, int32_t n, int32_t id);          /* TDTGreedyDecoder.logSoftmax (:149-172) */
+float qasr_transducer_confidence(const float* log_probs, int32_t n);           /* min(1, exp(mean log-prob)), 0 when n == 0 */
+
+/* SentencePiece-style vocabularies of these models (vocab.json: {"0": "\u2581the", ...}).  style 0: ParakeetVocabulary
+ * (Sources/ParakeetASR/Vocabulary.swift:42-96); style 1: NemotronVocabulary = ParakeetEOUVocabulary
+ * (Sources/NemotronStreamingASR/Vocabulary.swift:31-77).  Pure CPU. */
+typedef struct qasr_sp_vocab qasr_sp_vocab;
+int qasr_sp_vocab_create(const int32_t* ids, const char* const* pieces, size_t n, int style, qasr_sp_vocab** out);
+int qasr_sp_vocab_load(const char* vocab_json_path, int style, qasr_sp_vocab** out);
+void qasr_sp_vocab_destroy(qasr_sp_vocab* v);
+int qasr_sp_vocab_count(const qasr_sp_vocab* v);
+int qasr_sp_vocab_decode(const qasr_sp_vocab* v, const int32_t* ids, int32_t n, char* buf, size_t cap);        /* bytes written or -1 */
+/* decodeWords: words '\n'-joined into buf, one confidence per word; returns the word count or -1 (buffer / conf_cap too small) */
+int qasr_sp_vocab_decode_words(const qasr_sp_vocab* v, const int32_t* ids, int32_t n_ids, const float* log_probs, int32_t n_log_probs,
+                               char* buf, size_t cap, float* confidences, int32_t conf_cap);
+
+/* sample bookkeeping of a streaming session (StreamingSession.pushAudio / finalize, Sources/NemotronStreamingASR/StreamingSession.swift:
+ * 110-139): whenever samples_per_chunk samples are buffered one chunk is cut and the buffer advances by `shift` samples
+ * (Nemotron 160 ms: 17 x 160 = 2720 and 2 x 8 x 160 = 2560; Parakeet-EOU 320 ms: 33 x 160 = 5280 and 4 x 8 x 160 = 5120).  Pure CPU. */
+typedef struct qasr_stream_chunker qasr_stream_chunker;
+int qasr_stream_chunker_create(int32_t samples_per_chunk, int32_t shift, qasr_stream_chunker** out);
+void qasr_stream_chunker_destroy(qasr_stream_chunker* c);
+int qasr_stream_chunker_push(qasr_stream_chunker* c, const float* samples, size_t n);
+int qasr_stream_chunker_pop(qasr_stream_chunker* c, float* chunk);       /* 1: chunk[samples_per_chunk] filled; 0: not enough samples */
+int qasr_stream_chunker_flush(qasr_stream_chunker* c, float* chunk);     /* finalize: 1: the zero-padded remainder; 0: buffer was empty */
+size_t qasr_stream_chunker_buffered(const qasr_stream_chunker* c);
 
 #ifdef __cplusplus
 }

@@ -122,13 +122,6 @@ void Engine::finalize_decoder() {
     decw_ = DecW{};
     decw_.quant = tensors_.count("model.embed_tokens.scales") > 0;
     decw_.norm = wptr("model.norm.weight", {H});
-    auto new_buf = [&](size_t bytes) {
-        auto b = std::make_unique<DevBuf>();
-        b->alloc(bytes);
-        void* p = b->p;
-        fused_.push_back(std::move(b));
-        return p;
-    };
     if (decw_.quant) {
         decw_.embed_raw = quant_raw("model.embed_tokens", cfg_.vocab, H);
         if (!aligner) decw_.embed_q = quant_image(decw_.embed_raw);

@@ -15,77 +15,15 @@
 // Kernel 2 (mel_finalize): clamp/scale with the per-clip max and transpose [frame][mel] ->
 // [mel][frame] through an LDS tile so both sides stay coalesced.
 #include "mel.h"
-#include <math.h>
-#include <vector>
+#include "mel_core.h"
 
 namespace qasr {
-
-// ---- table layout (float words) -----------------------------------------------------------
-constexpr int T_HANN = 0;                 // [400] (padded to 512)
-constexpr int T_TW256 = 512;              // [256][2] cos,sin(-2 pi k/256)
-constexpr int T_TW512 = T_TW256 + 512;    // [257][2] cos,sin(-2 pi k/512) (padded to 520)
-constexpr int T_FBSTART = T_TW512 + 520;  // [128] int: first bin of mel m
-constexpr int T_FBLEN = T_FBSTART + 128;  // [128] int: number of bins
-constexpr int T_FBWOFF = T_FBLEN + 128;   // [128] int: offset into packed weights
-constexpr int T_FBW = T_FBWOFF + 128;     // [FBW_CAP] packed weights
-constexpr int FBW_CAP = 640;
-constexpr int T_SCALE2 = T_FBW + FBW_CAP; // [1] fft_scale^2
-constexpr int T_TOTAL = T_SCALE2 + 8;
-
-static float hz_to_mel(float hz) {        // AudioPreprocessing.swift:72-78 (Float32)
-    if (hz < 1000.0f) return 3.0f * hz / 200.0f;
-    return 15.0f + logf(hz / 1000.0f) * (27.0f / logf(6.4f));
-}
-static float mel_to_hz(float mel) {       // :80-86
-    if (mel < 15.0f) return 200.0f * mel / 3.0f;
-    return 1000.0f * expf((mel - 15.0f) * (logf(6.4f) / 27.0f));
-}
 
 void MelTables::build(float fft_scale) {
     std::vector<float> t(T_TOTAL, 0.0f);
     for (int i = 0; i < MEL_NFFT; ++i)    // :41-44
         t[T_HANN + i] = 0.5f * (1.0f - cosf(2.0f * (float)M_PI * (float)i / 400.0f));
-    for (int k = 0; k < 256; ++k) {
-        double a = -2.0 * M_PI * k / 256.0;
-        t[T_TW256 + 2 * k] = (float)cos(a);
-        t[T_TW256 + 2 * k + 1] = (float)sin(a);
-    }
-    for (int k = 0; k <= 256; ++k) {
-        double a = -2.0 * M_PI * k / 512.0;
-        t[T_TW512 + 2 * k] = (float)cos(a);
-        t[T_TW512 + 2 * k + 1] = (float)sin(a);
-    }
-    // slaney filterbank on the 512-point grid (:88-153), float32 like the reference
-    const int npts = MEL_NMELS + 2;
-    float mel_min = hz_to_mel(0.0f), mel_max = hz_to_mel(16000.0f / 2.0f);
-    std::vector<float> filt(npts), diff(npts - 1);
-    for (int i = 0; i < npts; ++i) filt[i] = mel_to_hz(mel_min + (float)i * (mel_max - mel_min) / (float)(npts - 1));
-    for (int i = 0; i < npts - 1; ++i) diff[i] = filt[i + 1] - filt[i];
-    int* fb_start = reinterpret_cast<int*>(&t[T_FBSTART]);
-    int* fb_len = reinterpret_cast<int*>(&t[T_FBLEN]);
-    int* fb_woff = reinterpret_cast<int*>(&t[T_FBWOFF]);
-    int w = 0;
-    for (int m = 0; m < MEL_NMELS; ++m) {
-        float enorm = 2.0f / (filt[m + 2] - filt[m]);
-        int first = -1, last = -1;
-        std::vector<float> row(MEL_NBINS);
-        for (int k = 0; k < MEL_NBINS; ++k) {
-            float f = (float)k * 16000.0f / 512.0f;
-            float down = (f - filt[m]) / diff[m];
-            float up = (filt[m + 2] - f) / diff[m + 1];
-            float v = fmaxf(0.0f, fminf(down, up)) * enorm;
-            row[k] = v;
-            if (v != 0.0f) { if (first < 0) first = k; last = k; }
-        }
-        fb_start[m] = first < 0 ? 0 : first;
-        fb_len[m] = first < 0 ? 0 : last - first + 1;
-        fb_woff[m] = w;
-        for (int k = fb_start[m]; k < fb_start[m] + fb_len[m]; ++k) {
-            if (w >= FBW_CAP) throw std::runtime_error("mel filterbank exceeds FBW_CAP");
-            t[T_FBW + w++] = row[k];
-        }
-    }
-    t[T_SCALE2] = fft_scale * fft_scale;
+    melc_fill_tables(t, fft_scale * fft_scale);     // twiddles, slaney filterbank on the 512-point grid (:88-153), power scale
     bytes = T_TOTAL * sizeof(float);
     QASR_HIP(hipMalloc(&dev, bytes));
     QASR_HIP(hipMemcpy(dev, t.data(), bytes, hipMemcpyHostToDevice));
@@ -108,9 +46,6 @@ __device__ __forceinline__ float ordered_f32(unsigned u) {
 constexpr int MEL_WAVES = 4;              // frames in flight per workgroup
 constexpr int MEL_FPW = 8;                // frames per wave (sequential)
 
-struct cplx { float re, im; };
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-
 __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frames_kernel(
     const float* __restrict__ tab, const float* __restrict__ pcm, const long* __restrict__ pcm_off,
     const int* __restrict__ n_samples, const int* __restrict__ frame_off, float* __restrict__ raw,
@@ -131,9 +66,6 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frames_kernel(
     float* out = raw + (long)frame_off[b] * MEL_NMELS;
     const float2* tw256 = reinterpret_cast<const float2*>(&s_tab[T_TW256]);
     const float2* tw512 = reinterpret_cast<const float2*>(&s_tab[T_TW512]);
-    const int* fb_start = reinterpret_cast<const int*>(&s_tab[T_FBSTART]);
-    const int* fb_len = reinterpret_cast<const int*>(&s_tab[T_FBLEN]);
-    const int* fb_woff = reinterpret_cast<const int*>(&s_tab[T_FBWOFF]);
     const float scale2 = s_tab[T_SCALE2];
     float2* bufA = s_buf[wave][0];
     float2* bufB = s_buf[wave][1];
@@ -163,61 +95,13 @@ __global__ __launch_bounds__(MEL_WAVES * 64) void mel_frames_kernel(
             }
             v[r] = {a0, a1};
         }
-        // ---- 256-point complex FFT: Stockham radix-4, Ns = 1, 4, 16, 64 ---------------------
-        float2* src = bufA;
-        float2* dst = bufB;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int Ns = 1 << (2 * pass);
-            if (pass > 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { float2 t = src[lane + 64 * r]; v[r] = {t.x, t.y}; }
-            }
-            const int k = lane & (Ns - 1);
-            const int tstep = k * (64 / Ns);              // twiddle w256^(tstep * r)
-#pragma unroll
-            for (int r = 1; r < 4; ++r) {
-                float2 t = tw256[(tstep * r) & 255];
-                v[r] = cmul(v[r], {t.x, t.y});
-            }
-            cplx t0 = {v[0].re + v[2].re, v[0].im + v[2].im};
-            cplx t1 = {v[0].re - v[2].re, v[0].im - v[2].im};
-            cplx t2 = {v[1].re + v[3].re, v[1].im + v[3].im};
-            cplx t3 = {v[1].im - v[3].im, -(v[1].re - v[3].re)};     // (v1 - v3) * (-i)
-            const int base = (lane / Ns) * Ns * 4 + k;
-            dst[base] = make_float2(t0.re + t2.re, t0.im + t2.im);
-            dst[base + Ns] = make_float2(t1.re + t3.re, t1.im + t3.im);
-            dst[base + 2 * Ns] = make_float2(t0.re - t2.re, t0.im - t2.im);
-            dst[base + 3 * Ns] = make_float2(t1.re - t3.re, t1.im - t3.im);
-            __syncthreads();
-            float2* tmp = src; src = dst; dst = tmp;
-        }
-        // `src` now holds Z[0..255]
-        // ---- split into the 512-point real spectrum, power ----------------------------------
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = lane + 64 * r;
-            float2 zk = src[k];
-            float2 zn = src[(256 - k) & 255];
-            float er = 0.5f * (zk.x + zn.x), ei = 0.5f * (zk.y - zn.y);        // E = (Z[k] + conj Z[N-k]) / 2
-            float orr = 0.5f * (zk.y + zn.y), oi = -0.5f * (zk.x - zn.x);      // O = (Z[k] - conj Z[N-k]) / (2i)
-            float2 w = tw512[k];
-            float xr = er + (orr * w.x - oi * w.y);
-            float xi = ei + (orr * w.y + oi * w.x);
-            pw[k] = (xr * xr + xi * xi) * scale2;
-            if (k == 0) {                                                      // Nyquist: E[0] - O[0]
-                float nr = er - orr;
-                pw[256] = nr * nr * scale2;
-            }
-        }
-        __syncthreads();
+        // ---- 512-point real FFT of the frame -> power spectrum in pw (mel_core.h) --------------
+        melc_frame_power(v, lane, bufA, bufB, pw, tw256, tw512, scale2);
         // ---- sparse slaney filterbank + log10 ------------------------------------------------
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int m = lane + 64 * h;
-            const int s0 = fb_start[m], len = fb_len[m], wo = fb_woff[m];
-            float acc = 0.0f;
-            for (int i = 0; i < len; ++i) acc += pw[s0 + i] * s_tab[T_FBW + wo + i];
+            const float acc = melc_filter(s_tab, pw, m);
             float lg = log10f(fmaxf(acc, 1e-10f));
             if (live) {
                 out[(long)frame * MEL_NMELS + m] = lg;

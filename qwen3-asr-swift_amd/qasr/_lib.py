@@ -54,6 +54,19 @@ class QasrAlignment(C.Structure):
                 ("raw_indices", C.POINTER(C.c_int32)), ("n_indices", C.c_size_t), ("passes", C.c_int32)]
 
 
+class QasrTransducerConfig(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("blank_id", C.c_int32), ("eou_id", C.c_int32), ("n_durations", C.c_int32),
+                ("durations", C.c_int32 * 8), ("first_text_id", C.c_int32), ("max_symbols", C.c_int32)]
+
+
+TD_DECODER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)
+TD_JOINT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+
+
+class QasrTransducerCallbacks(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("decoder_step", TD_DECODER_FN), ("joint", TD_JOINT_FN)]
+
+
 SC_TRANSCRIBE_FN = C.CFUNCTYPE(ScTranscriptionResult, C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int)
 SC_RATE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p)
 
@@ -135,6 +148,31 @@ SIGNATURES = {
     "qasr_ctc_timings": (C.c_int, [_E, _F]),
     "qasr_ctc_greedy": (C.c_int, [_F, C.c_int32, C.c_int32, C.c_int32, _I]),
     "qasr_layer_normalize": (C.c_int, [_F, C.c_size_t, C.c_float, _F]),
+    "qasr_nemo_mel_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_float, _P(_E)]),
+    "qasr_nemo_mel_destroy": (None, [_E]),
+    "qasr_nemo_mel_last_error": (C.c_char_p, [_E]),
+    "qasr_nemo_mel_num_frames": (C.c_int, [C.c_size_t]),
+    "qasr_nemo_mel_length": (C.c_int, [C.c_size_t]),
+    "qasr_nemo_mel_extract": (C.c_int, [_E, C.c_int, _P(_F), _P(C.c_size_t), C.c_size_t, _I, _F, C.c_size_t, _I, C.c_int]),
+    "qasr_nemo_mel_reset_stats": (C.c_int, [_E, C.c_int]),
+    "qasr_nemo_mel_timing": (C.c_int, [_E, _F, _P(C.c_int)]),
+    "qasr_transducer_default_config": (C.c_int, [C.c_char_p, _P(QasrTransducerConfig)]),
+    "qasr_tdt_greedy_decode": (C.c_int, [_P(QasrTransducerConfig), _P(QasrTransducerCallbacks), C.c_int32, _I, _F, C.c_int32, _F]),
+    "qasr_rnnt_greedy_decode": (C.c_int, [_P(QasrTransducerConfig), _P(QasrTransducerCallbacks), C.c_int32, C.c_int32, _I, _F, C.c_int32, _I]),
+    "qasr_log_softmax_at": (C.c_float, [_F, C.c_int32, C.c_int32]),
+    "qasr_transducer_confidence": (C.c_float, [_F, C.c_int32]),
+    "qasr_sp_vocab_create": (C.c_int, [_I, _P(C.c_char_p), C.c_size_t, C.c_int, _P(_E)]),
+    "qasr_sp_vocab_load": (C.c_int, [C.c_char_p, C.c_int, _P(_E)]),
+    "qasr_sp_vocab_destroy": (None, [_E]),
+    "qasr_sp_vocab_count": (C.c_int, [_E]),
+    "qasr_sp_vocab_decode": (C.c_int, [_E, _I, C.c_int32, C.c_char_p, C.c_size_t]),
+    "qasr_sp_vocab_decode_words": (C.c_int, [_E, _I, C.c_int32, _F, C.c_int32, C.c_char_p, C.c_size_t, _F, C.c_int32]),
+    "qasr_stream_chunker_create": (C.c_int, [C.c_int32, C.c_int32, _P(_E)]),
+    "qasr_stream_chunker_destroy": (None, [_E]),
+    "qasr_stream_chunker_push": (C.c_int, [_E, _F, C.c_size_t]),
+    "qasr_stream_chunker_pop": (C.c_int, [_E, _F]),
+    "qasr_stream_chunker_flush": (C.c_int, [_E, _F]),
+    "qasr_stream_chunker_buffered": (C.c_size_t, [_E]),
 }
 
 _lib = None
