@@ -43,16 +43,63 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def host_cpu_info():
+    """Physical cores / logical CPUs of the node and the CPUs this process may use (core count stated)."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = logical
+    cores, model = set(), None
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif k == "model name" and model is None:
+                model = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    quota = None                       # cgroup CPU quota of this container (cpu.max: "<quota> <period>" or "max <period>")
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return {"physical_cores": len(cores) or logical, "logical_cpus": logical, "affinity_cpus": affinity,
+            "cgroup_cpu_quota": None if quota is None else round(quota, 2), "model": model}
+
+
 def cpu_baseline(sd, pcm, n_dec):
     """CPU restatement of the reference (oracle/, B=1 sequential like the Swift reference) timed on
     this host's cores on ONE clip of the benchmark batch.  Checker code, used here only as the
     reported baseline -- never on the product path."""
     from oracle import config as OC, pipeline, precision as P
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))       # the GPU box grants a 16-core share per GPU
+    host = host_cpu_info()
+    avail = host["affinity_cpus"]
+    # every physical core this process may run on (SMT siblings add nothing to an fp32 BLAS workload); a GPU box grants a share of
+    # its cores per GPU, so the affinity mask, not the socket, is what "the node's own host CPU cores" means for one rank
+    threads = max(1, min(avail, host["physical_cores"]))
+    if host["cgroup_cpu_quota"]:       # a container's share of the node (the GPU boxes grant 16 CPUs per GPU): more threads than that only thrash
+        threads = max(1, min(threads, int(host["cgroup_cpu_quota"])))
+    threads = min(threads, 64)         # B = 1 fp32 GEMMs at these widths stop scaling well before that; `host` states the node's real counts
     torch.set_num_threads(threads)
     model = pipeline.OracleModel(sd, OC.AUDIO_SMALL, OC.TEXT_SMALL, OC.TOKENS, P.REFERENCE)
     # bounded sample: the first two thirds of one clip with two thirds of the forced tokens, ~10 s of CPU work on 16 cores
@@ -67,7 +114,7 @@ def cpu_baseline(sd, pcm, n_dec):
     dt = time.perf_counter() - t0
     assert len(toks) == n_dec
     return {"value": round(len(pcm) / 16000.0 / dt, 3), "unit": "audio-seconds/sec", "cores": threads,
-            "kind": "port",
+            "host": host, "kind": "port",
             "sample": f"{num}/{frac} of one of the batch's clips ({len(pcm) / 16000.0:.0f} s, {n_dec} forced tokens), B=1 "
                       f"sequential like the reference, fp32 torch-CPU restatement (not the Swift binary), "
                       f"{dt:.1f} s of CPU work"}
@@ -101,14 +148,64 @@ def stage_roofline(B, seconds, n_dec, stage_ms, steps, bits=16):
     return out
 
 
-def kernel_source_stamp():
-    """sha256 (first 16 hex) of the decode-attention kernel's sources (its own translation unit and the headers it includes): a PMC traffic file is only quoted for the kernels it was
-    measured on (profiles/*_pmc_traffic.json carries the stamp of the build it was taken from)."""
+def kernel_source_stamp(files=("dec_attention.hip", "dec_rope.h", "dec_kernels.h", "common.h")):
+    """sha256 (first 16 hex) of a kernel's sources (its own translation unit and the headers it includes; default: the decode attention):
+    a PMC traffic file is only quoted for the kernels it was measured on (profiles/*_pmc_traffic.json carries the stamp of the build it
+    was taken from)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("dec_attention.hip", "dec_rope.h", "dec_kernels.h", "common.h"):
+    for f in files:
         h.update(open(os.path.join(ROOT, "qwen3-asr-swift_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+GEMV_SOURCES = ("dec_gemv.hip", "dec_epilogue.h", "dec_kernels.h", "common.h")
+
+# Omnilingual-ASR-CTC (BASELINE configs[3]): FLOPs per clip as scratch/bench_ctc.py counts them -- conv stack 2 C k C_in per output frame
+# of each layer, projection, positional conv, per layer 2 (4 D^2 + 2 D F) + 4 T D attention, head 2 D V per encoder frame
+W2V_KERNELS, W2V_STRIDES = (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)
+
+
+def omnilingual_flops(cfg, n):
+    C_, D, F, V = cfg.feature_dim, cfg.model_dim, cfg.ffn_dim, cfg.vocab
+    L, total = n, 0.0
+    for i, (k, st) in enumerate(zip(W2V_KERNELS, W2V_STRIDES)):
+        L = (L - k) // st + 1
+        total += 2.0 * L * C_ * k * (1 if i == 0 else C_)
+    T = L
+    total += 2.0 * T * D * C_ + 2.0 * T * D * cfg.pos_kernel * (D // cfg.pos_groups)
+    total += cfg.layers * (2.0 * T * (4 * D * D + 2 * D * F) + 4.0 * T * T * D)
+    total += 2.0 * T * D * V
+    return total, T
+
+
+def omnilingual_leg(variant, B, seconds, steps, device):
+    """configs[3]: `B` clips x `seconds` s through the wav2vec2-CTC engine of the named variant (seeded random weights streamed in, synthetic
+    waveforms), timed region = pcm in host memory -> collapsed token ids in host memory; MFMA fraction of the whole pass."""
+    from qasr.omnilingual import OmnilingualASRMLXModel
+    t0 = time.perf_counter()
+    m = OmnilingualASRMLXModel.from_synthetic(variant=variant, device=device, max_batch=B, max_audio_seconds=int(np.ceil(seconds)))
+    log(f"omnilingual {variant}: weights built + uploaded in {time.perf_counter() - t0:.1f} s")
+    try:
+        clips = [synth.synth_waveform(k, seconds) for k in range(B)]
+        m.transcribe_batch(clips)                                # warm-up
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ids = m.transcribe_batch(clips)
+        dt = (time.perf_counter() - t0) / steps
+        ms = m.timings()
+        fl, T = omnilingual_flops(m.cfg, len(clips[0]))
+        return {"metric": f"audio-seconds/sec Omnilingual-ASR-CTC-{variant}, {seconds:.0f} s @ 16 kHz, b={B}, 1 GPU (BASELINE configs[3])",
+                "value": round(B * seconds / dt, 1), "unit": "audio-seconds/sec", "steps": steps, "ms_per_step": round(dt * 1e3, 2),
+                "stage_ms": {"frontend": round(ms[0], 2), "transformer": round(ms[1], 2), "head_argmax": round(ms[2], 2), "device_total": round(ms[3], 2)},
+                "frames_per_clip": T, "tflop_per_step": round(B * fl / 1e12, 2),
+                "roofline": {"bound": "mfma", "achieved": round(B * fl / dt / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(B * fl / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                             "note": "whole pass (front end, attention, LayerNorm, head and host collapse included) against the dense bf16 MFMA peak"},
+                "ids_per_clip": [len(t) for t in ids[:4]], "data": "synthetic", "dtype": "bf16 MFMA operands, f32 residual / LayerNorm / softmax",
+                "parameters": f"{variant} (layers {m.cfg.layers}, model_dim {m.cfg.model_dim}, ffn {m.cfg.ffn_dim}, heads {m.cfg.heads})"}
+    finally:
+        m.close()
 
 
 def run_leg(model, clips, n_dec, steps, warmup, world, gathered, inclusive):
@@ -129,7 +226,8 @@ def main():
     ap.add_argument("--bits", type=int, default=16, choices=[16, 8, 4],
                     help="weights of the HEADLINE engine: 16 = bf16 (BASELINE's config), 4 / 8 = MLX-quantised decoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the b=1 / b=8 and MLX-4bit legs (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the b=1 / b=8, MLX-4bit and Omnilingual legs (profiling runs)")
+    ap.add_argument("--omnilingual", default="300M,7B", help="comma-separated Omnilingual-ASR-CTC variants for the configs[3] legs ('' = none)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,6 +298,20 @@ def main():
             break
         if traffic is None:
             traffic_note = f"no PMC file under profiles/ matches the current kernel sources ({stamp}); not quoted"
+        # which kernel dominates the GPU time of a pass: the decode attention (one launch per layer and step) or the decode-step GEMV
+        # kernel (decode_gemv2_kernel, four launches per layer and step: q|k|v, o-proj, gate|up, down).  Shares from the live probes
+        # (HIP events on the engine stream; the GEMV probe walks the layers so that every launch streams its weights from HBM as in situ)
+        n_layers = model.cfg.dec_layers
+        res_ms = dt_res / args.steps * 1e3
+        gemv_ms, gemv_bytes = probe["layer_gemv"]
+        share_attn = n_layers * steps_done * dom_ms / res_ms
+        share_gemv = n_layers * steps_done * gemv_ms / res_ms
+        gemv_family = {"kernel": "decode_gemv2_kernel x4 per layer (q|k|v + o-proj + gate|up + down: one decoder layer's weights, streamed "
+                                 "once per step for all batch rows)",
+                       "achieved": round(gemv_bytes / gemv_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(gemv_bytes / gemv_ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_layer": gemv_bytes,
+                       "avg_ms_per_layer": round(gemv_ms, 5), "avg_ms_per_launch": round(gemv_ms / 4, 5),
+                       "share_of_gpu_time": round(share_gemv, 3)}
         wname = "bf16" if args.bits == 16 else f"MLX {args.bits}-bit decoder (packed in HBM), bf16 activations"
         out = {
             "metric": "audio-seconds/sec (RTF^-1) Qwen3-ASR-0.6B, 30 s@16 kHz, b=32 per GPU",
@@ -222,19 +334,29 @@ def main():
             "resident_value": round(audio_s / dt_res, 1),
             "resident_note": "same passes with the batch already in HBM (qasr_batch_rewind): no staging copy / H2D / planning timed",
             "stage_roofline": stage_roofline(B, args.seconds, n_dec, stage_ms, steps_done, args.bits),
-            "roofline": {"bound": "hbm",
-                         "kernel": "decode_attention_mfma_kernel (one launch = one decoder layer's attention for all batch rows: "
-                                   "K and V rows of every row's context are streamed once)",
-                         "achieved": round(dom_bytes / dom_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_note,
-                         "bytes_per_launch": dom_bytes, "avg_ms_per_launch": round(dom_ms, 5),
-                         "how": "algorithmic bytes = sum_b 2 (K,V) x 8 kv heads x 128 x 2 B x ctx_b at the probe's context; duration = HIP "
-                                "events on the engine stream around each of 20 launches, each preceded by an untimed weight-streaming "
-                                "launch as in the real step (qasr_kernel_probe)",
-                         "other": {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)}
-                                   for k, v in probe.items()}},
         }
+        attn_obj = {"bound": "hbm",
+                    "kernel": "decode_attention_mfma_kernel (one launch = one decoder layer's attention for all batch rows: "
+                              "K and V rows of every row's context are streamed once)",
+                    "achieved": round(dom_bytes / dom_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_note,
+                    "bytes_per_launch": dom_bytes, "avg_ms_per_launch": round(dom_ms, 5),
+                    "share_of_gpu_time": round(share_attn, 3),
+                    "how": "algorithmic bytes = sum_b 2 (K,V) x 8 kv heads x 128 x 2 B x ctx_b at the probe's context; duration = HIP "
+                           "events on the engine stream around each of 20 launches, each preceded by an untimed weight-streaming "
+                           "launch as in the real step (qasr_kernel_probe)"}
+        other = {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)} for k, v in probe.items()}
+        if share_gemv > share_attn:
+            # the GEMV kernel takes more of the pass than the attention: IT is the dominant kernel and the object's headline figure;
+            # the attention (closer to its roofline) is kept beside it, never instead of it
+            out["roofline"] = {"bound": "hbm", **gemv_family, "traffic": None,
+                               "traffic_source": "PMC traffic of this kernel: profiles/ (per-kernel CSV of the round); not re-derived here",
+                               "how": "algorithmic bytes = the bf16 weights of one decoder layer (8.39 + 4.19 + 12.58 + 6.29 MB); duration = HIP events "
+                                      "on the engine stream around 20 x 4 launches walking the 28 layers (weights from HBM, as in the step)",
+                               "attention": attn_obj, "other": other}
+        else:
+            out["roofline"] = {**attn_obj, "family": gemv_family, "other": other}
         if extras:
             out["batches"] = extras
     model.close()
@@ -254,6 +376,15 @@ def main():
                            "note": "synthetic weights quantised with mlx's affine scheme (group 64); decode-step products in the "
                                    "reference's f32-dequantised form, prompt pass on bf16(scale*q+bias) like its many-row kernel"}
         m4.close()
+    if rank == 0 and world == 1 and not args.no_extras and args.omnilingual:
+        # BASELINE configs[3]: the wav2vec2-CTC family at the same batch x clip length, one engine at a time (the Qwen3 engines are closed)
+        out["omnilingual"] = {}
+        for variant in [v for v in args.omnilingual.split(",") if v]:
+            try:
+                out["omnilingual"][variant] = omnilingual_leg(variant, B, min(args.seconds, 40.0), 3, local_rank)
+                log(f"omnilingual {variant}: {out['omnilingual'][variant]['value']} audio-s/s")
+            except Exception as ex:      # noqa: BLE001 -- a failed side leg must not lose the headline line
+                out["omnilingual"][variant] = {"error": str(ex)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, clips[0], n_dec)

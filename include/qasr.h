@@ -203,6 +203,28 @@ int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double
 int qasr_gemm_probe(qasr_engine* e, const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int K, int form,
                     int reps, float* out, float* avg_ms);
 
+/* ---- utterance-batch data parallelism inside one process ----------------------------------------------------------------------
+ * Replaces the sequential file loop of `speech transcribe-batch` (Sources/AudioCLILib/TranscribeBatchCommand.swift:82-93) for a caller
+ * that owns several GPUs: one engine (= one HIP device + one stream, weights replicated) and one host thread per listed device; clips
+ * are independent (Qwen3ASR.swift:131-164), so device i takes the contiguous block [lo_i, hi_i) of the list (the first B % n devices one
+ * clip more) and there is no data-path exchange.  The gather of the decoded token streams is each engine's device -> host copy of its
+ * [rows, max_new_tokens + 1] int32 block straight into the caller's buffer.  (The one-process-per-GPU form of the same partition, with
+ * the RCCL all_gather of that block over xGMI, is bench.py / qasr/dist.py.)  A device may be listed twice (two engines on one GPU). */
+typedef struct qasr_dp qasr_dp;
+/* cfg->device is ignored (devices[i] is used); model_dir as for qasr_create (NULL: fill with qasr_dp_set_tensor + qasr_dp_finalize). */
+int qasr_dp_create(const char* model_dir, const qasr_config* cfg, const int32_t* devices, int32_t n_devices, qasr_dp** out);
+void qasr_dp_destroy(qasr_dp* dp);
+int qasr_dp_n_devices(const qasr_dp* dp);
+qasr_engine* qasr_dp_engine(qasr_dp* dp, int32_t i);               /* borrowed: engine i (vocabulary, options, stage entry points) */
+const char* qasr_dp_last_error(const qasr_dp* dp);                 /* dp may be NULL: last create() failure */
+int qasr_dp_set_tensor(qasr_dp* dp, const char* name, const void* host_data, int dtype, const int64_t* shape, int ndim);   /* every engine */
+int qasr_dp_finalize(qasr_dp* dp);
+/* tokens [B, max_new_tokens + 1], lens [B] as for qasr_transcribe_batch; B may exceed n_devices x max_batch (blocks go through an
+ * engine in slices of its capacity).  Results are identical to qasr_transcribe_batch on one engine (batch invariance). */
+int qasr_dp_transcribe_batch(qasr_dp* dp, const float* const* pcm, const size_t* n, size_t B, int sample_rate, const qasr_options* opt,
+                             int32_t* tokens, int32_t* lens);
+int qasr_dp_timings(const qasr_dp* dp, float* ms_per_engine, int32_t cap);    /* wall time of each engine's share of the last call */
+
 /* ---- tuning / diagnostic knobs ----------------------------------------------------------------
  * Process-wide A/B switches between kept kernel variants (csrc/tuning.h lists them with their measurements: "gemm_nbuf",
  * "gemv_splitb", "use_graph", ...).  Defaults are the measured winners; every value passes the parity tests.  Each knob

@@ -8,10 +8,6 @@
 
 using qasr::Engine;
 
-struct qasr_engine {
-    std::unique_ptr<Engine> impl;
-};
-
 static thread_local std::string g_create_error;
 
 static int fail(qasr_engine* e, int code, const std::string& msg) {
@@ -19,8 +15,10 @@ static int fail(qasr_engine* e, int code, const std::string& msg) {
     return code;
 }
 
+// every guarded entry first makes the engine's device current for the calling thread (the HIP current device is per thread: an engine
+// per GPU may be driven from any thread, e.g. the worker threads of qasr_dp_*)
 #define QASR_GUARD(e, body)                                                          \
-    try { body; return QASR_OK; }                                                    \
+    try { (e)->impl->bind_device(); body; return QASR_OK; }                          \
     catch (const qasr::HipError& ex) { return fail(e, QASR_ERR_HIP, ex.what()); }    \
     catch (const qasr::NotLoaded& ex) { return fail(e, QASR_ERR_NOT_LOADED, ex.what()); } \
     catch (const std::invalid_argument& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); } \
@@ -297,6 +295,7 @@ int qasr_align_raw(qasr_engine* e, const float* pcm, size_t n, const int32_t* sl
     if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
     QASR_GUARD(e, {
         std::vector<std::vector<int32_t>> raw;
+        e->impl->bind_device();
         e->impl->align_forward(&pcm, &n, 1, {std::vector<int32_t>(slotted_ids, slotted_ids + n_ids)},
                                {std::vector<int32_t>(ts_positions, ts_positions + n_ts)}, raw, logits);
         if (!raw.empty()) std::memcpy(raw_indices, raw[0].data(), raw[0].size() * sizeof(int32_t));
@@ -311,6 +310,7 @@ static int align_common(qasr_engine* e, const float* pcm, size_t n, int sample_r
     if (!e->impl->loaded()) return fail(e, QASR_ERR_NOT_LOADED, "weights not finalized");
     QASR_GUARD(e, {
         const std::string text = long_text ? long_text : "";
+        e->impl->bind_device();
         const int passes = e->impl->align_words(pcm, n, pairs, long_form, long_text ? &text : nullptr);
         out->words = e->impl->al_view.data();
         out->n_words = e->impl->al_view.size();
@@ -351,6 +351,7 @@ int qasr_align_batch(qasr_engine* e, const float* const* pcm, const size_t* n, s
         catch (const std::exception& ex) { return fail(e, QASR_ERR_INVALID, ex.what()); }
     }
     QASR_GUARD(e, {
+        e->impl->bind_device();
         e->impl->align_batch(pcm, n, B, pairs);
         for (size_t b = 0; b < B; ++b) {
             auto& r = e->impl->al_batch[b];

@@ -2,8 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <set>
 #include <string>
 #include <stdexcept>
+#include <utility>
 
 namespace qasr {
 
@@ -142,5 +145,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel): a kernel's attributes live with the device's code object, and one
+// process may drive an engine per GPU (qasr_dp_*) from several threads
+inline void ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    QASR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return;
+    QASR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({dev, kernel});
+}
 
 }  // namespace qasr

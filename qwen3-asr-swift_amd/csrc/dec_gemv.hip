@@ -359,11 +359,7 @@ static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
         return false;
     } else {
         auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
         hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), a2.row_groups > 1 ? a2.row_groups : 1), dim3(WAVES * 64), lds, s, a2);
         return true;
     }

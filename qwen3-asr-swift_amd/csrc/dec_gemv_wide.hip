@@ -96,11 +96,7 @@ static void gemv_wide_go(const DecGemvArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)16 * (2 * (KSW * 8 * 32) + 16) + (size_t)7 * 1024;
     static_assert(lds <= 156 * 1024, "activation image + reduction scratch exceed the CU");
     auto kern = decode_gemv_wide_kernel<KSW, KPH, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(a.N / 16, (a.B + 15) / 16), dim3(512), lds, s, a);
 }
 

@@ -172,11 +172,7 @@ template <int K, int NB>
 static void lm_head_go(const LmHeadArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)NB * 16 * (2 * K + 16);
     auto kern = lm_head_kernel<K, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(lmh_grid()), dim3(LMH_WAVES * 64), lds, s, a);
 }
 

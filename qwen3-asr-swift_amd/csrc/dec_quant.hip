@@ -381,11 +381,7 @@ static bool gemvq_go(const DecGemvQArgs& a2, hipStream_t s) {
     constexpr size_t lds = gemvq_lds<BITS, WAVES, KBW, NT>();
     static_assert(lds <= 156 * 1024, "LDS image too large");
     auto kern = decode_gemvq_kernel<BITS, SBF32, NT, WAVES, KBW, PRO, EPI, KPH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), (a2.g.B + 15) / 16), dim3(WAVES * 64), lds, s, a2);
     return true;
 }

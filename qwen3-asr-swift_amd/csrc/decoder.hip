@@ -880,12 +880,16 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     // same launch shape as the captured step: one row group of the batch (see issue_decode_step)
     const int rows = decode_group_rows();
     const PromptW probe_w = (which == 3 || which == 4) ? prompt_weights(0, s) : PromptW{};
+    long probe_layer = 0;
     auto body = [&]() {
         DecGemvArgs a{};
         a.B = rows;
         auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) { decode_gemv(epi, a, qi, norm_w, d_dh_.as<bf16_t>(), s); };
         if (which == 0) {
-            // the same four launches as run_decode_step (residual epilogues write a scratch row block)
+            // the same four launches as run_decode_step (residual epilogues write a scratch row block), one LAYER AFTER THE OTHER like
+            // the step: a layer's 31 MB come back only after the other layers' 0.85 GB went through the caches, so every launch streams
+            // its weights from HBM as in situ (one layer in a loop would sit in the Infinity Cache and time 15 % short)
+            const DecLayerW& L = decw_.layers[(size_t)(probe_layer++ % cfg_.dec_layers)];
             a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
             gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
             a.W = L.wo; a.Wp = L.wo_p; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();

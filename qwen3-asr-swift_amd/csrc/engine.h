@@ -76,6 +76,7 @@ public:
     ~Engine();
 
     const qasr_config& config() const { return cfg_; }
+    void bind_device() const { QASR_HIP(hipSetDevice(cfg_.device)); }
     hipStream_t stream() const { return stream_; }
     std::string last_error;
 
@@ -292,3 +293,8 @@ std::vector<int32_t> aligner_enforce_monotonicity(const int32_t* raw, size_t n);
 int aligner_find_trailing_plateau(const float* start_times, size_t n, float tolerance, int min_size);
 
 }  // namespace qasr
+
+// the C ABI's engine handle (api.cpp, api_dp.cpp)
+struct qasr_engine {
+    std::unique_ptr<qasr::Engine> impl;
+};

@@ -281,12 +281,17 @@ __global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 
 // 256 bytes of zeros in HBM for masked direct-to-LDS chunks (one per translation unit)
 inline const bf16_t* gemm_zero_block() {
-    static bf16_t* z = nullptr;
-    if (!z) {
-        QASR_HIP(hipMalloc(&z, 256));
-        QASR_HIP(hipMemset(z, 0, 256));
+    static std::mutex mu;
+    static bf16_t* z[64] = {};                 // one block per device (an engine per GPU in one process: qasr_dp_*)
+    int dev = 0;
+    QASR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) throw std::invalid_argument("device ordinal outside [0, 64)");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!z[dev]) {
+        QASR_HIP(hipMalloc(&z[dev], 256));
+        QASR_HIP(hipMemset(z[dev], 0, 256));
     }
-    return z;
+    return z[dev];
 }
 // LDS buffers of the glds kernel for a launch of `grid` tiles.  1: 32 KiB + 124 VGPRs -> 4 workgroups per CU, the loads
 // of one overlap the MFMAs of the others (encoder 18.1 -> 15.6 ms, prompt pass 20.8 -> 18.9 ms at 32 x 30 s against the

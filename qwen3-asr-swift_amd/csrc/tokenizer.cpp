@@ -10,22 +10,22 @@ namespace qasr {
 
 // GPT-2 byte -> unicode table inverted: code point -> byte, or -1 (Tokenizer.swift:146-181)
 static int unicode_to_byte(unsigned cp) {
-    static int table[0x200];
-    static bool init = false;
-    if (!init) {
-        for (auto& t : table) t = -1;
+    struct Table { int v[0x200]; };
+    static const Table table = [] {               // initialised once, thread-safely (engines may detokenise from several threads)
+        Table t;
+        for (auto& x : t.v) x = -1;
         bool direct[256] = {};
         for (int b = 33; b <= 126; ++b) direct[b] = true;
         for (int b = 0xA1; b <= 0xAC; ++b) direct[b] = true;
         for (int b = 0xAE; b <= 0xFF; ++b) direct[b] = true;
         int n = 0;
         for (int b = 0; b < 256; ++b) {
-            if (direct[b]) table[b] = b;
-            else table[0x100 + n++] = b;
+            if (direct[b]) t.v[b] = b;
+            else t.v[0x100 + n++] = b;
         }
-        init = true;
-    }
-    return cp < 0x200 ? table[cp] : -1;
+        return t;
+    }();
+    return cp < 0x200 ? table.v[cp] : -1;
 }
 
 // decode one UTF-8 code point from a well-formed std::string (tokens come from JSON / callers)
@@ -127,17 +127,18 @@ static void put_cp(std::string& s, unsigned cp) {
 
 // GPT-2 byte -> unicode (Tokenizer.swift:146-172)
 static unsigned byte_to_unicode(unsigned char b) {
-    static unsigned table[256];
-    static bool init = false;
-    if (!init) {
+    struct Table { unsigned v[256]; };
+    static const Table tbl = [] {
+        Table t;
         bool direct[256] = {};
         for (int x = 33; x <= 126; ++x) direct[x] = true;
         for (int x = 0xA1; x <= 0xAC; ++x) direct[x] = true;
         for (int x = 0xAE; x <= 0xFF; ++x) direct[x] = true;
         int n = 0;
-        for (int x = 0; x < 256; ++x) table[x] = direct[x] ? (unsigned)x : 0x100u + n++;
-        init = true;
-    }
+        for (int x = 0; x < 256; ++x) t.v[x] = direct[x] ? (unsigned)x : 0x100u + n++;
+        return t;
+    }();
+    const unsigned* table = tbl.v;
     return table[b];
 }
 

@@ -148,6 +148,15 @@ SIGNATURES = {
     "qasr_ctc_timings": (C.c_int, [_E, _F]),
     "qasr_ctc_greedy": (C.c_int, [_F, C.c_int32, C.c_int32, C.c_int32, _I]),
     "qasr_layer_normalize": (C.c_int, [_F, C.c_size_t, C.c_float, _F]),
+    "qasr_dp_create": (C.c_int, [C.c_char_p, _P(QasrConfig), _I, C.c_int32, _P(_E)]),
+    "qasr_dp_destroy": (None, [_E]),
+    "qasr_dp_n_devices": (C.c_int, [_E]),
+    "qasr_dp_engine": (_E, [_E, C.c_int32]),
+    "qasr_dp_last_error": (C.c_char_p, [_E]),
+    "qasr_dp_set_tensor": (C.c_int, [_E, C.c_char_p, C.c_void_p, C.c_int, _P(C.c_int64), C.c_int]),
+    "qasr_dp_finalize": (C.c_int, [_E]),
+    "qasr_dp_transcribe_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(QasrOptions), _I, _I]),
+    "qasr_dp_timings": (C.c_int, [_E, _F, C.c_int32]),
     "qasr_nemo_mel_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_float, _P(_E)]),
     "qasr_nemo_mel_destroy": (None, [_E]),
     "qasr_nemo_mel_last_error": (C.c_char_p, [_E]),

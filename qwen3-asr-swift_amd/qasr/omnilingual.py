@@ -61,6 +61,20 @@ class OmnilingualASRMLXModel:
         m._check(m.lib.qasr_ctc_finalize(m.h))
         return m
 
+    @classmethod
+    def from_synthetic(cls, variant="300M", device=0, seed=0, **capacity):
+        """Seeded random weights of the named variant streamed tensor by tensor into the engine (benchmarks: no checkpoint offline)."""
+        from . import synth
+        m = cls(variant=variant, device=device, **capacity)
+
+        def put(name, t):
+            t = t.contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            m._check(m.lib.qasr_ctc_set_tensor(m.h, name.encode(), C.c_void_p(t.data_ptr()), 0, shape, t.dim()))
+        synth.synth_omnilingual_state_dict(m.cfg, seed=seed, bits=0, sink=put)
+        m._check(m.lib.qasr_ctc_finalize(m.h))
+        return m
+
     def _check(self, rc):
         if rc != 0:
             raise QasrError(f"qasr error {rc}: {self.lib.qasr_ctc_last_error(self.h).decode()}")

@@ -141,14 +141,26 @@ def quantize_state_dict(sd, bits, group=QUANT_GROUP):
     return out
 
 
-def synth_omnilingual_state_dict(cfg, seed=0, bits=0, dtype=torch.float32):
+class _TensorSink(dict):
+    """dict stand-in that hands every assigned tensor to a callback and keeps nothing (a 7B variant is 26 GB of f32 on the host otherwise)."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def __setitem__(self, name, tensor):
+        self.fn(name, tensor)
+
+
+def synth_omnilingual_state_dict(cfg, seed=0, bits=0, dtype=torch.float32, sink=None):
     """Seeded random weights of an Omnilingual (wav2vec2-CTC) model under the reference's fairseq2 tensor names
     (MLX/OmnilingualMLXWeightLoader.swift:40-135): PyTorch Conv1d layout [out, in, k], weight_g / weight_v for the
     positional conv, every encoder / head Linear with a bias.  cfg: object with model_dim, layers, heads, ffn_dim,
     feature_dim, pos_kernel, pos_groups, vocab.  bits 4 / 8: the encoder and head linears as MLX triplets (f32 scales, as
-    the reference's loader widens them), else float weights."""
+    the reference's loader widens them), else float weights.  sink(name, tensor): stream the tensors to a consumer instead of returning
+    them (same seeded values in the same order)."""
     g = torch.Generator().manual_seed(seed)
-    sd = {}
+    sd = {} if sink is None else _TensorSink(sink)
     kernels = (10, 3, 3, 3, 3, 2, 2)
 
     def rnd(*shape, std):

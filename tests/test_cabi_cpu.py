@@ -215,3 +215,20 @@ def test_wav_reference_fixture():
     assert abs(float(np.abs(s).max()) - 0.715) < 0.01
     active = np.nonzero(np.abs(s) > 0.02)[0]
     assert 5.0 < active[0] / r < 5.4 and 8.2 < active[-1] / r < 8.5
+
+
+def test_dp_argument_checks_without_a_gpu():
+    """qasr_dp_*: argument validation is host code (no device is touched before it passes)."""
+    lib = _lib.load()
+    cfg = _lib.QasrConfig()
+    assert lib.qasr_default_config(b"tiny", C.byref(cfg)) == 0
+    h = C.c_void_p()
+    dev = (C.c_int32 * 2)(0, 0)
+    assert lib.qasr_dp_create(None, None, dev, 2, C.byref(h)) != 0
+    assert lib.qasr_dp_create(None, C.byref(cfg), None, 2, C.byref(h)) != 0
+    assert lib.qasr_dp_create(None, C.byref(cfg), dev, 0, C.byref(h)) != 0
+    assert lib.qasr_dp_create(None, C.byref(cfg), dev, 65, C.byref(h)) != 0
+    assert lib.qasr_dp_n_devices(None) == 0 and lib.qasr_dp_engine(None, 0) is None
+    assert lib.qasr_dp_transcribe_batch(None, None, None, 0, 16000, None, None, None) != 0
+    assert lib.qasr_dp_finalize(None) != 0 and lib.qasr_dp_set_tensor(None, b"x", None, 0, None, 0) != 0
+    lib.qasr_dp_destroy(None)

@@ -24,7 +24,7 @@ def _wave(k, seconds):
     return synth.synth_waveform(k, seconds)
 
 
-def _check_logits(m, sd, cfg, pcm, what):
+def _check_logits(m, sd, cfg, pcm, what, bar_dev=1e-2, bar_ref=2e-2, sure_frac=0.5):
     got = m.logits(pcm)
     W = O.OmniWeights(sd)
     with torch.no_grad():
@@ -35,10 +35,10 @@ def _check_logits(m, sd, cfg, pcm, what):
     rr = np.linalg.norm(got - ref) / np.linalg.norm(ref)
     tol = float(np.abs(got - dev).max())
     print(f"{what}: rel-L2 vs DEVICE {rd:.2e} vs REFERENCE {rr:.2e}, max|d| {tol:.3e}")
-    assert rd < 1e-2 and rr < 2e-2
+    assert rd < bar_dev and rr < bar_ref
     top2 = np.sort(dev, axis=1)[:, -2:]
     sure = (top2[:, 1] - top2[:, 0]) > 2 * tol
-    assert (got.argmax(1)[sure] == dev.argmax(1)[sure]).all() and sure.mean() > 0.5
+    assert (got.argmax(1)[sure] == dev.argmax(1)[sure]).all() and sure.mean() > sure_frac
     return got
 
 
@@ -139,6 +139,41 @@ def test_7b_width_one_layer():
         clips = [_wave(k, 1.1 + 1.9 * k) for k in range(3)]
         out = m.transcribe_batch(clips)
         assert [m.transcribe_batch([c])[0] for c in clips] == out
+    finally:
+        m.close()
+
+
+def test_7b_width_sixteen_layers_deep():
+    """Depth: the 7B widths with SIXTEEN transformer layers on a 10 s clip against the oracle under both rounding policies -- what 16
+    consecutive bf16-operand residual updates (the stated deviation of this path: f32 residual stream, bf16 MFMA operands) cost at the
+    logits.  The per-layer error adds roughly like a random walk (1 layer: 3-4e-3 vs DEVICE), so the bars are the one-layer bars x 2.5;
+    per-frame argmax must still agree wherever the oracle's own top-2 margin exceeds the logit tolerance."""
+    cfg = dataclasses.replace(O.VARIANTS["7B"], layers=16)
+    sd = synth.synth_omnilingual_state_dict(cfg, seed=23)
+    m = OmnilingualASRMLXModel.from_state_dict(sd, variant="7B", layers=16, max_batch=2, max_audio_seconds=10)
+    try:
+        pcm = _wave(4, 10.0)
+        _check_logits(m, sd, cfg, pcm, "7B width, 16 layers, 10 s", bar_dev=2.5e-2, bar_ref=5e-2, sure_frac=0.3)
+        a = m.transcribe_batch([pcm, _wave(5, 4.2)])
+        assert a == m.transcribe_batch([pcm, _wave(5, 4.2)]) and a[0] == m.transcribe_batch([pcm])[0]
+    finally:
+        m.close()
+
+
+def test_7b_full_geometry_32_clips_30s_properties():
+    """BASELINE configs[3] at its full size: Omnilingual-ASR-CTC-7B (128 layers, D 2048), 32 clips x 30 s in one pass.  No oracle can
+    afford 128 layers x 48 k frames; what the domain offers at this size: every clip's id count is bounded by its frame count (1499),
+    the pass is deterministic, and clips do not interact -- two clips alone give the ids they gave inside the batch of 32."""
+    m = OmnilingualASRMLXModel.from_synthetic(variant="7B", max_batch=32, max_audio_seconds=30)
+    try:
+        clips = [_wave(k, 30.0 if k % 5 else 27.3) for k in range(32)]
+        a = m.transcribe_batch(clips)
+        ms = m.timings()
+        assert len(a) == 32 and all(0 < len(t) <= m.num_frames(len(c)) for t, c in zip(a, clips))
+        assert m.transcribe_batch(clips) == a
+        for k in (0, 17):
+            assert m.transcribe_batch([clips[k]])[0] == a[k], k
+        print(f"7B, 32 x 30 s: device {ms[3]:.0f} ms per pass, ids per clip {[len(t) for t in a[:4]]}")
     finally:
         m.close()
 
