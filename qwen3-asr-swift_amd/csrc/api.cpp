@@ -11,6 +11,8 @@ using qasr::Engine;
 static thread_local std::string g_create_error;
 
 static int fail(qasr_engine* e, int code, const std::string& msg) {
+    // a reported HIP failure must not stay behind as the runtime's sticky "last error" (a later launch check would blame itself for it)
+    if (code == QASR_ERR_HIP) (void)hipGetLastError();
     if (e && e->impl) e->impl->last_error = msg; else g_create_error = msg;
     return code;
 }
@@ -87,7 +89,7 @@ int qasr_create(const char* model_dir, const qasr_config* cfg, qasr_engine** out
     try {
         e->impl.reset(new Engine(*cfg));
         if (model_dir) { e->impl->load_directory(model_dir); e->impl->finalize(); }
-    } catch (const qasr::HipError& ex) { g_create_error = ex.what(); delete e; return QASR_ERR_HIP; }
+    } catch (const qasr::HipError& ex) { g_create_error = ex.what(); delete e; (void)hipGetLastError(); return QASR_ERR_HIP; }
     catch (const std::exception& ex) { g_create_error = ex.what(); delete e; return model_dir ? QASR_ERR_IO : QASR_ERR_INVALID; }
     *out = e;
     return QASR_OK;
@@ -431,6 +433,7 @@ struct qasr_ctc_engine {
     std::unique_ptr<qasr::CtcEngine> impl;
 };
 static int cfail(qasr_ctc_engine* e, int code, const std::string& msg) {
+    if (code == QASR_ERR_HIP) (void)hipGetLastError();
     if (e && e->impl) e->impl->last_error = msg; else g_create_error = msg;
     return code;
 }
@@ -478,7 +481,7 @@ int qasr_ctc_create(const char* model_dir, const qasr_ctc_config* cfg, qasr_ctc_
     try {
         e->impl.reset(new qasr::CtcEngine(*cfg));
         if (model_dir) { e->impl->load_directory(model_dir); e->impl->finalize(); }
-    } catch (const qasr::HipError& ex) { g_create_error = ex.what(); delete e; return QASR_ERR_HIP; }
+    } catch (const qasr::HipError& ex) { g_create_error = ex.what(); delete e; (void)hipGetLastError(); return QASR_ERR_HIP; }
     catch (const std::exception& ex) { g_create_error = ex.what(); delete e; return model_dir ? QASR_ERR_IO : QASR_ERR_INVALID; }
     *out = e;
     return QASR_OK;

@@ -16,6 +16,7 @@ struct qasr_stream_chunker { qasr::StreamChunker c; };
 static thread_local std::string g_nemo_create_error;
 
 static int mfail(qasr_nemo_mel* m, int code, const std::string& msg) {
+    if (code == QASR_ERR_HIP) (void)hipGetLastError();
     if (m) m->last_error = msg; else g_nemo_create_error = msg;
     return code;
 }
@@ -71,7 +72,7 @@ int qasr_nemo_mel_create(int device, int max_streams, size_t max_samples, float 
     *out = nullptr;
     auto* m = new qasr_nemo_mel();
     try { m->impl = std::make_unique<qasr::NemoMel>(device, max_streams, (long)max_samples, fft_scale); }
-    catch (const qasr::HipError& ex) { g_nemo_create_error = ex.what(); delete m; return QASR_ERR_HIP; }
+    catch (const qasr::HipError& ex) { g_nemo_create_error = ex.what(); delete m; (void)hipGetLastError(); return QASR_ERR_HIP; }
     catch (const std::exception& ex) { g_nemo_create_error = ex.what(); delete m; return QASR_ERR_INVALID; }
     *out = m;
     return QASR_OK;
