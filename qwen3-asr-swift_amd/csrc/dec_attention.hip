@@ -27,7 +27,11 @@ __device__ __forceinline__ long vfrag_index(int key, int d) {
     return (((long)kb * DT + (d >> 4)) * 64 + (d & 15) + 16 * g) * 8 + half * 4 + j;
 }
 
-template <int HD, int WAVES, int UNR, bool SPEC>
+// EARLYQ: the loads of the token's own q / k / v rows, the norm weights and the rope row are requested BEFORE the K / V stream.  Vector
+// loads return in order, so in the other order the query math waits behind the whole K / V stream of its wave: in-kernel stamps at 1 clip
+// put "query ready" 5.2 us after the first wave's start (ctx_len round trip -> K / V from HBM -> q rows), with the sweep itself 0.85 us.
+// Same arithmetic either way (bit-identical results).
+template <int HD, int WAVES, int UNR, bool SPEC, bool EARLYQ>
 __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     const bf16_t* __restrict__ qkv, const int* __restrict__ ctx_len, int heads, int kv_heads,
     const bf16_t* __restrict__ qn_w, const bf16_t* __restrict__ kn_w, float eps, const float* __restrict__ rope_cos,
@@ -68,6 +72,44 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
                 vreg[u][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch * DT + dt) * 512);
         }
     };
+    const int nh = heads + 2 * kv_heads;
+    const bf16_t* row = qkv + (long)b * nh * HD;
+    const bool act = lane < HALF;
+    // raw loads only (no conversion, no select: either would need the data and put a wait in front of the K / V requests)
+    const int lc = act ? lane : 0;           // inactive lanes (head_dim < 128) read element 0 and are zeroed after the requests
+    float rc = 0.f, rs = 0.f;
+    bf16_t wr1 = 0, wr2 = 0, xr1[REP], xr2[REP], kxr1 = 0, kxr2 = 0, kwr1 = 0, kwr2 = 0;
+    bf16_t vown[(HD + 63) / 64];
+    auto load_own = [&]() {                  // this token's q rows (+ k or v row on the two append waves), norm weights, rope row
+        rc = rope_cos[(long)b * HALF + lc];
+        rs = rope_sin[(long)b * HALF + lc];
+        wr1 = qn_w[lc];
+        wr2 = qn_w[lc + HALF];
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            const bf16_t* src = row + (long)(kvh * REP + r) * HD;
+            xr1[r] = src[lc];
+            xr2[r] = src[lc + HALF];
+        }
+        // the k and v rows on EVERY wave (six 2-byte requests; only the two append waves use them): a wave-dependent branch here makes
+        // hipcc end it with a full wait for the values it defines, i.e. a round trip in front of the K / V requests of those two waves
+        {
+            const bf16_t* src = row + (long)(heads + kvh) * HD;
+            kxr1 = src[lc];
+            kxr2 = src[lc + HALF];
+            kwr1 = kn_w[lc];
+            kwr2 = kn_w[lc + HALF];
+        }
+        {
+            const bf16_t* src = row + (long)(heads + kv_heads + kvh) * HD;
+#pragma unroll
+            for (int i = 0; i < (HD + 63) / 64; ++i) vown[i] = src[lane + 64 * i < HD ? lane + 64 * i : 0];
+        }
+    };
+    if (EARLYQ) {
+        load_own();
+        __builtin_amdgcn_sched_barrier(0);   // keep these requests ahead of the K / V stream (in-order return)
+    }
     int pos;
     if (SPEC) {
         issue(wave, 0x7fffffff);             // before the position is known: rows past it are masked
@@ -77,24 +119,21 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
         issue(wave, (pos + 31) >> 5);
     }
     const int nchunks = (pos + 31) >> 5;
-    const int nh = heads + 2 * kv_heads;
-    const bf16_t* row = qkv + (long)b * nh * HD;
+    if (EARLYQ) __builtin_amdgcn_sched_barrier(0);
+    else load_own();
+    if (!act) { rc = 0.f; rs = 0.f; }
+    const float w1 = act ? bf16_to_f32(wr1) : 0.0f, w2 = act ? bf16_to_f32(wr2) : 0.0f;
+    float x1[REP], x2[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) { x1[r] = act ? bf16_to_f32(xr1[r]) : 0.0f; x2[r] = act ? bf16_to_f32(xr2[r]) : 0.0f; }
+    const float kx1 = act ? bf16_to_f32(kxr1) : 0.0f, kx2 = act ? bf16_to_f32(kxr2) : 0.0f;
+    const float kw1 = act ? bf16_to_f32(kwr1) : 0.0f, kw2 = act ? bf16_to_f32(kwr2) : 0.0f;
     // ---- the two query heads: norm + rope on every wave, bf16 image in this wave's LDS slice ------------
-    const bool act = lane < HALF;
-    const float rc = act ? rope_cos[(long)b * HALF + lane] : 0.0f, rs = act ? rope_sin[(long)b * HALF + lane] : 0.0f;
     float qa[REP][2];
     {
-        const float w1 = act ? bf16_to_f32(qn_w[lane]) : 0.0f, w2 = act ? bf16_to_f32(qn_w[lane + HALF]) : 0.0f;
-        float x1[REP], x2[REP];
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
-            const bf16_t* src = row + (long)(kvh * REP + r) * HD;
-            x1[r] = act ? bf16_to_f32(src[lane]) : 0.0f;
-            x2[r] = act ? bf16_to_f32(src[lane + HALF]) : 0.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < REP; ++r) {
-            const float inv = rsqrtf(wave_sum(x1[r] * x1[r] + x2[r] * x2[r]) / (float)HD + eps);
+            const float inv = rsqrtf(lane_sum<64>(x1[r] * x1[r] + x2[r] * x2[r]) / (float)HD + eps);
             norm_rope_pair(x1[r], x2[r], w1, w2, inv, rc, rs, qa[r][0], qa[r][1]);
             if (act) {
                 s_q[wave][r][lane] = f32_to_bf16(qa[r][0]);
@@ -102,30 +141,33 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
             }
         }
     }
-    // ---- the token's own key (wave WAVES-1) and value (wave WAVES-2): cache append + merge terms -------
-    if (wave == WAVES - 1) {
-        const bf16_t* src = row + (long)(heads + kvh) * HD;
-        const float x1 = act ? bf16_to_f32(src[lane]) : 0.0f, x2 = act ? bf16_to_f32(src[lane + HALF]) : 0.0f;
-        const float inv = rsqrtf(wave_sum(x1 * x1 + x2 * x2) / (float)HD + eps);
+    // ---- the token's own key and value: cache append (waves WAVES-1 / WAVES-2) + merge terms -----------
+    // The arithmetic runs on every wave and only the stores are wave-dependent: with the USES inside a wave-dependent branch hipcc sinks
+    // the k / v row requests into it, i.e. behind the K / V stream (in-order return: the append waves would sit out the whole stream
+    // before they could start).  It all happens while that stream is in flight.
+    {
+        const float inv = rsqrtf(lane_sum<64>(kx1 * kx1 + kx2 * kx2) / (float)HD + eps);
         float k1, k2;
-        norm_rope_pair(x1, x2, act ? bf16_to_f32(kn_w[lane]) : 0.0f, act ? bf16_to_f32(kn_w[lane + HALF]) : 0.0f, inv, rc, rs, k1, k2);
-        if (act) {
+        norm_rope_pair(kx1, kx2, kw1, kw2, inv, rc, rs, k1, k2);
+        if (wave == WAVES - 1 && act) {
             bf16_t* dk = cache.k + cache.off(b, kvh, pos);
             dk[lane] = f32_to_bf16(k1);
             dk[lane + HALF] = f32_to_bf16(k2);
         }
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
-            const float d = wave_sum(act ? qa[r][0] * k1 + qa[r][1] * k2 : 0.0f);
-            if (lane == 0) s_new[r] = d * scale;
+            const float d = lane_sum<64>(act ? qa[r][0] * k1 + qa[r][1] * k2 : 0.0f);
+            if (wave == WAVES - 1 && lane == 0) s_new[r] = d * scale;
         }
-    } else if (wave == WAVES - 2) {
-        const bf16_t* src = row + (long)(heads + kv_heads + kvh) * HD;
         bf16_t* dvf = cache.vf + cache.off(b, kvh, 0);
-        for (int i = lane; i < HD; i += 64) {
-            const bf16_t v = src[i];
-            s_vn[i] = bf16_to_f32(v);
-            dvf[vfrag_index<HD>(pos, i)] = v;
+#pragma unroll
+        for (int ii = 0; ii < (HD + 63) / 64; ++ii) {
+            const int i = lane + 64 * ii;
+            if (i < HD) {
+                const bf16_t v = vown[ii];
+                s_vn[i] = bf16_to_f32(v);                        // every wave writes the same value
+                if (wave == WAVES - 2) dvf[vfrag_index<HD>(pos, i)] = v;
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -258,17 +300,23 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     dim3 grid(kv_heads, B);
     // A/B knobs: waves per workgroup (8 with two chunks in flight per wave | 16 with one) and speculative first loads
     const int nw = tuning().da_waves;
-    const int spec = tuning().da_spec;
-#define QASR_DAM_GO(HD_, W_, U_, S_)                                                                                         \
-    hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, kv_heads, \
+    // da_spec: 0 never | 1 always | 2 auto: only while the launch is latency-bound (few batch rows: the wasted bytes of chunks past the
+    // context cost nothing there, and the K / V round trip no longer waits for the ctx_len round trip)
+    const int spec_knob = tuning().da_spec;
+    const bool spec = spec_knob == 1 || (spec_knob == 2 && B <= 8);
+    const bool early = tuning().da_earlyq != 0;
+#define QASR_DAM_GO(HD_, W_, U_, S_, E_)                                                                                         \
+    hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_, E_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, kv_heads, \
                        qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg)
     if (hd == 128) {
-        if (nw == 16 && spec) QASR_DAM_GO(128, 16, 1, true);
-        else if (nw == 16) QASR_DAM_GO(128, 16, 1, false);
-        else if (spec) QASR_DAM_GO(128, 8, 2, true);
-        else QASR_DAM_GO(128, 8, 2, false);
+        if (nw == 16 && spec) QASR_DAM_GO(128, 16, 1, true, true);
+        else if (nw == 16) QASR_DAM_GO(128, 16, 1, false, true);
+        else if (spec && early) QASR_DAM_GO(128, 8, 2, true, true);
+        else if (spec) QASR_DAM_GO(128, 8, 2, true, false);
+        else if (early) QASR_DAM_GO(128, 8, 2, false, true);
+        else QASR_DAM_GO(128, 8, 2, false, false);
     } else if (hd == 32) {
-        QASR_DAM_GO(32, 8, 1, false);
+        QASR_DAM_GO(32, 8, 1, false, true);
     } else
         throw std::invalid_argument("decode attention: unsupported head_dim");
 #undef QASR_DAM_GO

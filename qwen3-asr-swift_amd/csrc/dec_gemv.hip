@@ -120,7 +120,10 @@ struct DecGemv2Args {
 // PARTIAL (host: fewer than 16 batch rows, norm prologue): batch rows past the end get a zero image without the ~250 vector instructions of
 // the normalisation, so the waves that own live rows have the SIMDs to themselves (1 / 8 clips: decode -1.5 %); as a run-time branch in
 // the one kernel it cost the full-tile launches 3 % (profiles/r02_ab_gemv_skip_dead_rows.txt), hence a separate instantiation
-template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false>
+// EARLYW (host: at most 8 batch rows): the weight stream is requested WITHOUT waiting for the activation rows.  With a full batch that
+// order loses in the real step (see mask_x below); with a few rows X is a couple of KB, nothing queues behind it, and the launch is the
+// serial chain  X back (1.4 us) -> weights requested -> weights back (1.9 us)  that this overlaps (in-kernel stamps at 1 clip, round 3).
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false, bool EARLYW = false>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     DecGemvArgs a = a2.g;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     };
     // ---- 1. activation loads, then (once they are back, see mask_x) ALL weight fragments ------------------
     issue_x(0);
-    mask_x(0);
+    if (!EARLYW) mask_x(0);
     uint4 w[NT][KSW];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
                 }
         }
     }
+    if (EARLYW) mask_x(0);
     f32x4 acc[NT][NB];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -352,13 +356,13 @@ constexpr size_t gemv2_lds() {
     return (size_t)(ALLROWS ? 16 * NB : 16) * (2 * (KSW * WAVES * 32) + 16) + (size_t)(WAVES - 1) * NT * NB * 1024;
 }
 
-template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false>
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false, bool EARLYW = false>
 static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
     constexpr size_t lds = gemv2_lds<NT, NB, WAVES, KSW, ALLROWS>();
     if constexpr (lds > 156 * 1024) {
         return false;
     } else {
-        auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL>;
+        auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL, EARLYW>;
         ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
         hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), a2.row_groups > 1 ? a2.row_groups : 1), dim3(WAVES * 64), lds, s, a2);
         return true;
@@ -384,8 +388,13 @@ static bool gemv2_nb(const DecGemv2Args& a2, hipStream_t s) {
     constexpr bool fit2 = gemv2_lds<NT, 2, WAVES, KSW, true>() <= 150 * 1024 && NT * KSW * 4 + 2 * KSW * 4 <= 170;
     switch (nb) {
         case 1:
-            if constexpr (PRO == DEC_PRO_RMSNORM && EPI != DEC_EPI_LOGITS) {
-                if (a2.g.B < 16 && tuning().gemv_partial) return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, true>(a2, s);
+            if constexpr (EPI != DEC_EPI_LOGITS) {
+                const bool earlyw = a2.g.B <= 8 && tuning().gemv_earlyw;
+                if constexpr (PRO == DEC_PRO_RMSNORM) {
+                    if (a2.g.B < 16 && tuning().gemv_partial)
+                        return earlyw ? gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, true, true>(a2, s) : gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, true>(a2, s);
+                }
+                if (earlyw) return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, false, true>(a2, s);
             }
             return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI>(a2, s);
         case 2:

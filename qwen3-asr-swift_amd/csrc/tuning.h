@@ -12,9 +12,12 @@ struct Tuning {
     int gemv_splitb = 2;     // decode GEMV batch row groups on gridDim.y: 0 none | 1 residual GEMVs | 2 all
     int gemv_w1024 = 8;      // waves per workgroup for K = 1024 (8 x 4 k-steps | 4 x 8)
     int gemv_partial = 1;    // fewer than 16 batch rows: norm GEMVs skip the normalisation of rows past the end (own instantiation) | 0 off
+    int gemv_earlyw = 1;     // at most 8 batch rows: the weight stream requested without waiting for the activation rows | 0 after them (as at 16+ rows)
     int gemv_wide = 1;       // K = 6144 (1.7B down-projection): 1 two-phase LDS image, weights in registers (dec_gemv_wide.hip) | 0 generic kernel
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
-    int da_spec = 0;         // 1: first K/V loads issued before ctx_len is known
+    int da_spec = 1;         // first K/V loads issued before ctx_len is known: 1 always (round 3: -2 % decode at 1 / 8 clips, 0 ... -1.6 % at 32) |
+                             // 0 never | 2 up to 8 batch rows only
+    int da_earlyq = 0;       // 1: the token's own q / k / v rows requested ahead of the K / V stream (loads return in order; +-0, measured) | 0 after it
     int pa_form = 2;         // prompt attention: 2 transposed-score form | 1 first form (a third, 32x32x16 form was measured and dropped:
                              // profiles/r02_ab_prompt_attention_form3.txt)
     int pa_order = 1;        // prompt attention workgroup order: 1 longest query tiles first, kv head = XCD | 0 query tile fastest
