@@ -181,6 +181,13 @@ int32_t qasr_pick_next_token(const float* logits, int32_t vocab, const int32_t* 
 int qasr_batch_begin(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B,
                      const qasr_options* opt);          /* host -> HBM, builds the batch plan */
 int qasr_batch_run(qasr_engine* e);                     /* mel + encoder + prefill + greedy decode, async */
+/* Software pipeline over consecutive batches (a serving loop; no reference counterpart -- it loads and transcribes one file at a time):
+ * qasr_batch_stage copies the NEXT batch's clips into a second pinned buffer and queues their host -> HBM copy on a copy stream behind
+ * the current batch's log-mel (the only reader of the device PCM buffer), so that staging + PCIe run under the current batch's encoder /
+ * prompt pass / decode.  Call it after qasr_batch_run of the current batch (QASR_ERR_INVALID before that); qasr_batch_begin_staged then
+ * adopts the staged batch (planning only) once the current batch's tokens have been read.  Same results as qasr_batch_begin. */
+int qasr_batch_stage(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B);
+int qasr_batch_begin_staged(qasr_engine* e, const qasr_options* opt);
 /* Re-arm the resident batch (PCM + plans stay in HBM, greedy state is reset on the device) so that
  * qasr_batch_run can be timed repeatedly without host->device traffic.  No reference counterpart. */
 int qasr_batch_rewind(qasr_engine* e);

@@ -159,6 +159,14 @@ int qasr_batch_begin(qasr_engine* e, const float* const* pcm, const size_t* n, s
     for (size_t b = 0; b < B; ++b) if (n[b] == 0 || !pcm[b]) return fail(e, QASR_ERR_EMPTY_AUDIO, "empty clip in batch");
     QASR_GUARD(e, e->impl->batch_begin(pcm, n, B, opt));
 }
+int qasr_batch_stage(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B) {
+    if (!e || !pcm || !n) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->batch_stage(pcm, n, B));
+}
+int qasr_batch_begin_staged(qasr_engine* e, const qasr_options* opt) {
+    if (!e) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->batch_begin_staged(opt));
+}
 int qasr_batch_run(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_run()); }
 int qasr_batch_rewind(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_rewind()); }
 int qasr_batch_sync(qasr_engine* e) { if (!e) return QASR_ERR_INVALID; QASR_GUARD(e, e->impl->batch_sync()); }

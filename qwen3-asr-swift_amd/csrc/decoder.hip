@@ -506,6 +506,8 @@ void Engine::align_forward(const float* const* pcm, const size_t* n, size_t B,
     QASR_HIP(hipEventRecord(ev_[0], s));
     run_mel();
     QASR_HIP(hipEventRecord(ev_[1], s));
+    if (ev_mel_done_) QASR_HIP(hipEventRecord(ev_mel_done_, s));       // the device PCM / meta buffers are free for the next staged batch
+    run_issued_ = true;
     run_encoder();
     QASR_HIP(hipEventRecord(ev_[2], s));
     run_prefill(false);
@@ -811,11 +813,40 @@ void Engine::batch_begin(const float* const* pcm, const size_t* n, size_t B, con
     // at the end: the uploads run under the host-side planning and the kernels of qasr_batch_run queue behind them.
     QASR_HIP(hipStreamSynchronize(stream_));
     upload_pcm(pcm, n, B);
+    plan_batch(opt, max_tokens);
+}
+
+void Engine::plan_batch(const qasr_options* opt, int max_tokens) {
     plan_encoder();
     std::vector<int> n_audio;
     for (auto& c : clips_) n_audio.push_back(c.n_tokens);
     plan_prefill(opt, n_audio);
     reset_greedy_state(max_tokens, opt && opt->ignore_eos);
+}
+
+// qasr_batch_begin_staged: adopt the batch qasr_batch_stage uploaded ahead; only the planning is left to do here.
+void Engine::batch_begin_staged(const qasr_options* opt) {
+    if (!finalized_) throw std::runtime_error("weights not finalized");
+    require_asr("transcribe");
+    if (!staged_valid_) throw std::invalid_argument("batch_begin_staged: no staged batch (qasr_batch_stage, or it was overwritten by qasr_batch_begin)");
+    int max_tokens = opt && opt->max_tokens > 0 ? opt->max_tokens : cfg_.max_new_tokens;
+    if (max_tokens > cfg_.max_new_tokens) throw std::length_error("max_tokens exceeds engine capacity");
+    opt_rep_penalty_ = opt && opt->repetition_penalty != 0.0f ? opt->repetition_penalty : 1.0f;
+    opt_ngram_ = opt ? opt->no_repeat_ngram_size : 0;
+    opt_temperature_ = opt ? opt->temperature : 0.0f;
+    opt_seed_ = opt ? opt->seed : 0;
+    slow_path_ = !(opt_rep_penalty_ == 1.0f && opt_ngram_ == 0 && opt_temperature_ == 0.0f);
+    QASR_HIP(hipStreamSynchronize(stream_));                    // plan buffers are reused per batch
+    clips_.swap(staged_clips_);
+    batch_ = staged_B_;
+    batch_max_frames_all_ = staged_max_frames_all_;
+    staged_valid_ = false;
+    run_issued_ = false;
+    d_pcm_off_ = d_meta_.as<long>();
+    d_n_samples_ = reinterpret_cast<int*>(d_pcm_off_ + batch_);
+    d_frame_off_ = d_n_samples_ + batch_;
+    QASR_HIP(hipStreamWaitEvent(stream_, ev_stage_done_, 0));   // the kernels of qasr_batch_run queue behind the staged copies
+    plan_batch(opt, max_tokens);
 }
 
 void Engine::batch_run() {
@@ -824,6 +855,8 @@ void Engine::batch_run() {
     QASR_HIP(hipEventRecord(ev_[0], s));
     run_mel();
     QASR_HIP(hipEventRecord(ev_[1], s));
+    if (ev_mel_done_) QASR_HIP(hipEventRecord(ev_mel_done_, s));       // the device PCM / meta buffers are free for the next staged batch
+    run_issued_ = true;
     run_encoder();
     QASR_HIP(hipEventRecord(ev_[2], s));
     run_prefill(slow_path_);

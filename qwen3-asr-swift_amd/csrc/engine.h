@@ -97,6 +97,9 @@ public:
 
     // batch pipeline (qasr_batch_*): H2D + plan | mel + encoder + prefill + greedy decode | D2H
     void batch_begin(const float* const* pcm, const size_t* n, size_t B, const qasr_options* opt);
+    void batch_stage(const float* const* pcm, const size_t* n, size_t B);
+    void batch_begin_staged(const qasr_options* opt);
+    void plan_batch(const qasr_options* opt, int max_tokens);
     void batch_run();
     void batch_rewind();
     void batch_sync();
@@ -179,6 +182,15 @@ private:
     long max_samples_ = 0;       // per clip capacity
     int max_frames_all_ = 0;
     HostBuf h_pcm_, h_meta_;
+    // batch staged ahead (qasr_batch_stage / qasr_batch_begin_staged): second pinned buffers, copy stream, hand-over events
+    HostBuf h_pcm2_, h_meta2_;
+    hipStream_t copy_stream_ = nullptr;
+    hipEvent_t ev_mel_done_ = nullptr, ev_stage_done_ = nullptr;
+    std::vector<ClipPlan> staged_clips_;
+    int staged_B_ = 0, staged_max_frames_all_ = 0;
+    bool staged_valid_ = false, run_issued_ = false;
+    void stage_pcm(const float* const* pcm, const size_t* n, size_t B, HostBuf& hp, HostBuf& hm, hipStream_t cs, std::vector<ClipPlan>& clips,
+                   int& max_frames_all);
     DevBuf d_pcm_, d_meta_, d_mel_raw_, d_gmax_, d_mel_;
     int mel_stride_ = 0;
     // device views into d_meta_ (ints/longs), rebuilt per batch

@@ -67,6 +67,9 @@ Engine::~Engine() {
         if (side_[i]) (void)hipStreamDestroy(side_[i]);
     }
     mel_tables_.release();
+    if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
+    if (ev_mel_done_) (void)hipEventDestroy(ev_mel_done_);
+    if (ev_stage_done_) (void)hipEventDestroy(ev_stage_done_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -98,6 +101,8 @@ void Engine::finalize() {
     drop_graph();
     fused_.clear();
     batch_ = 0;
+    staged_valid_ = false;
+    run_issued_ = false;
     h_ctx0_.clear();
     forced_ctx_ = 0;
     finalized_ = false;
@@ -114,6 +119,9 @@ void Engine::unload() {
     vfcache_.clear();
     d_vrows_.release();
     d_wscratch_.release();
+    if (copy_stream_) QASR_HIP(hipStreamSynchronize(copy_stream_));
+    staged_valid_ = false;
+    run_issued_ = false;
     batch_ = 0;
     h_ctx0_.clear();
     forced_ctx_ = 0;
@@ -134,17 +142,20 @@ size_t Engine::memory_footprint() const {
     return n;
 }
 
-void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
+// Clips of one batch -> pinned staging `hp` (+ offsets / sample counts / frame offsets in `hm`) -> the device PCM and meta buffers, queued on
+// `cs`.  Fills the clip plans; the caller adopts them.
+void Engine::stage_pcm(const float* const* pcm, const size_t* n, size_t B, HostBuf& hp, HostBuf& hm, hipStream_t cs, std::vector<ClipPlan>& clips,
+                       int& max_frames_all) {
     if ((int)B > cfg_.max_batch) throw std::invalid_argument("batch exceeds max_batch");
-    clips_.clear();
+    clips.clear();
     long off = 0;
-    long* h_off = h_meta_.as<long>();
+    long* h_off = hm.as<long>();
     int* h_ns = reinterpret_cast<int*>(h_off + B);
     int* h_fo = h_ns + B;
     int frame_off = 0;
-    batch_max_frames_all_ = 0;
+    max_frames_all = 0;
     for (size_t b = 0; b < B; ++b) {
-        if (n[b] == 0) throw std::invalid_argument("empty clip");
+        if (!pcm[b] || n[b] == 0) throw std::invalid_argument("empty clip");
         if ((long)n[b] > max_samples_) throw std::length_error("clip longer than max_audio_seconds");
         ClipPlan c = plan_clip(cfg_, (long)n[b], 0);
         h_off[b] = off;
@@ -152,10 +163,9 @@ void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
         h_fo[b] = frame_off;
         off += ((long)n[b] + 1) & ~1L;
         frame_off += c.frames_all;
-        batch_max_frames_all_ = std::max(batch_max_frames_all_, c.frames_all);
-        clips_.push_back(std::move(c));
+        max_frames_all = std::max(max_frames_all, c.frames_all);
+        clips.push_back(std::move(c));
     }
-    batch_ = (int)B;
     // caller memory (pageable) -> pinned staging -> HBM: 61 MB at 32 x 30 s, ~10 ms on one core and ~2.4 ms over PCIe.  Clips are
     // spread over a few threads (each owns whole clips; the staging buffer is private to this engine) and the batch goes in
     // up to four slices, the H2D copy of a slice queued as soon as it is staged: staging of slice i + 1 overlaps the copy of i.
@@ -166,7 +176,7 @@ void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
         for (size_t sidx = 0; sidx < nsl; ++sidx) {
             const size_t s0 = B * sidx / nsl, s1 = B * (sidx + 1) / nsl;
             auto copy_range = [&](size_t b0, size_t b1) {
-                for (size_t b = b0; b < b1; ++b) std::memcpy(h_pcm_.as<float>() + h_off[b], pcm[b], n[b] * sizeof(float));
+                for (size_t b = b0; b < b1; ++b) std::memcpy(hp.as<float>() + h_off[b], pcm[b], n[b] * sizeof(float));
             };
             const size_t nb = s1 - s0;
             const int t_n = (int)std::min<size_t>((size_t)nthr, nb);
@@ -177,17 +187,47 @@ void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
                 for (auto& th : pool) th.join();
             }
             const long e0 = h_off[s0], e1 = s1 < B ? h_off[s1] : off;
-            QASR_HIP(hipMemcpyAsync(d_pcm_.as<float>() + e0, h_pcm_.as<float>() + e0, (size_t)(e1 - e0) * sizeof(float), hipMemcpyHostToDevice,
-                                    stream_));
+            QASR_HIP(hipMemcpyAsync(d_pcm_.as<float>() + e0, hp.as<float>() + e0, (size_t)(e1 - e0) * sizeof(float), hipMemcpyHostToDevice, cs));
         }
     }
     size_t meta_bytes = B * (sizeof(long) + 2 * sizeof(int));
-    QASR_HIP(hipMemcpyAsync(d_meta_.p, h_meta_.p, meta_bytes, hipMemcpyHostToDevice, stream_));
+    QASR_HIP(hipMemcpyAsync(d_meta_.p, hm.p, meta_bytes, hipMemcpyHostToDevice, cs));
+}
+
+void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
+    staged_valid_ = false;                         // a batch staged ahead would find its device buffers overwritten
+    if (copy_stream_) QASR_HIP(hipStreamSynchronize(copy_stream_));   // ... and its copies must not land on top of this batch
+    stage_pcm(pcm, n, B, h_pcm_, h_meta_, stream_, clips_, batch_max_frames_all_);
+    batch_ = (int)B;
+    run_issued_ = false;
     d_pcm_off_ = d_meta_.as<long>();
     d_n_samples_ = reinterpret_cast<int*>(d_pcm_off_ + B);
     d_frame_off_ = d_n_samples_ + B;
 }
 
+// qasr_batch_stage: the NEXT batch's clips -> a second pinned buffer -> HBM on a copy stream, behind the current batch's log-mel (the only
+// reader of the device PCM / meta buffers), while the current batch's encoder / prompt pass / decode run.
+void Engine::batch_stage(const float* const* pcm, const size_t* n, size_t B) {
+    if (!finalized_) throw NotLoaded("weights not finalized");
+    require_asr("batch_stage");
+    if (B == 0) throw std::invalid_argument("empty batch");
+    if (batch_ > 0 && !run_issued_)
+        throw std::invalid_argument("batch_stage: the current batch has not been started yet (call qasr_batch_run first: its log-mel still needs the PCM buffer)");
+    if (!copy_stream_) {
+        QASR_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        QASR_HIP(hipEventCreateWithFlags(&ev_mel_done_, hipEventDisableTiming));
+        QASR_HIP(hipEventCreateWithFlags(&ev_stage_done_, hipEventDisableTiming));
+        h_pcm2_.alloc(h_pcm_.bytes);
+        h_meta2_.alloc(h_meta_.bytes);
+    }
+    staged_valid_ = false;
+    QASR_HIP(hipStreamSynchronize(copy_stream_));  // the previous staged batch's copies have left the second pinned buffer
+    if (run_issued_) QASR_HIP(hipStreamWaitEvent(copy_stream_, ev_mel_done_, 0));
+    stage_pcm(pcm, n, B, h_pcm2_, h_meta2_, copy_stream_, staged_clips_, staged_max_frames_all_);
+    QASR_HIP(hipEventRecord(ev_stage_done_, copy_stream_));
+    staged_B_ = (int)B;
+    staged_valid_ = true;
+}
 void Engine::run_mel() {
     MelBatch mb;
     mb.pcm = d_pcm_.as<float>();

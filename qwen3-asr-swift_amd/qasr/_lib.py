@@ -105,6 +105,8 @@ SIGNATURES = {
     "qasr_set_merges": (C.c_int, [_E, C.c_char_p]),
     "qasr_pick_next_token": (C.c_int32, [_F, C.c_int32, _I, C.c_int32, C.c_float, C.c_int32, C.c_float, _P(C.c_uint64)]),
     "qasr_batch_begin": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, _P(QasrOptions)]),
+    "qasr_batch_stage": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t]),
+    "qasr_batch_begin_staged": (C.c_int, [_E, _P(QasrOptions)]),
     "qasr_batch_run": (C.c_int, [_E]),
     "qasr_batch_rewind": (C.c_int, [_E]),
     "qasr_batch_sync": (C.c_int, [_E]),

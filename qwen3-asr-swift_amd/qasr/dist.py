@@ -71,7 +71,7 @@ def _device_sync():
         torch.cuda.synchronize()
 
 
-def timed_passes(model, clips, n_dec, steps, warmup, inclusive, gathered=None):
+def timed_passes(model, clips, n_dec, steps, warmup, inclusive, gathered=None, pipelined=False):
     """bench.py's timed region: `warmup` untimed + `steps` timed passes of the hot path over this rank's clips, bracketed
     by barrier + device synchronisation on both sides, MAX over ranks of the elapsed wall time.
 
@@ -79,17 +79,32 @@ def timed_passes(model, clips, n_dec, steps, warmup, inclusive, gathered=None):
     ends with the token ids on the host -- SURVEY.md section 8(d)'s timed region; otherwise the batch stays resident in HBM
     and qasr_batch_rewind re-arms it (the kernel-only figure).  gathered: [world * B, S] int32 tensor on the collective's
     device; every pass ends with the all_gather of this rank's [B, S] token block into it (the only exchange of the path).
+    pipelined (with inclusive): consecutive passes overlap like a serving loop -- while pass i's encoder / prompt pass / decode run, pass
+    i + 1's clips are staged from the caller's host buffers into pinned memory and copied to HBM (qasr_batch_stage), and pass i + 1 starts
+    with the planning only (qasr_batch_begin_staged).  Every pass still begins at host buffers and ends with token ids on the host; K passes
+    do K stagings, K uploads and K full computations.
     -> (seconds, lens of the last pass)."""
     import time
     world = dist.get_world_size() if dist.is_initialized() else 1
+    staged = {"ready": False}
 
     def one_pass():
-        if inclusive:
-            model.batch_begin(clips, max_tokens=n_dec, ignore_eos=True)
+        if inclusive and pipelined:
+            if staged["ready"]:
+                model.batch_begin_staged(max_tokens=n_dec, ignore_eos=True)
+            else:
+                model.batch_begin(clips, max_tokens=n_dec, ignore_eos=True)
+            model.batch_run()
+            model.batch_stage(clips)                          # the next pass's input, under this pass's kernels
+            staged["ready"] = True
+            toks, lens = model.batch_tokens()
         else:
-            model.batch_rewind()
-        model.batch_run()
-        toks, lens = model.batch_tokens()                     # D2H, waits for the engine stream
+            if inclusive:
+                model.batch_begin(clips, max_tokens=n_dec, ignore_eos=True)
+            else:
+                model.batch_rewind()
+            model.batch_run()
+            toks, lens = model.batch_tokens()                 # D2H, waits for the engine stream
         if gathered is not None:
             block = torch.from_numpy(toks).to(gathered.device, non_blocking=True)
             if world > 1:

@@ -184,6 +184,20 @@ class Qwen3ASRModel:
         self._check(self.lib.qasr_batch_begin(self.h, ptrs, ns, B, C.byref(o)))
         self._B = B
 
+    def batch_stage(self, clips):
+        """Stage the NEXT batch under the current one (qasr_batch_stage); adopt it with batch_begin_staged()."""
+        self._staged = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        B = len(self._staged)
+        ptrs = (C.POINTER(C.c_float) * B)(*[_fptr(c) for c in self._staged])
+        ns = (C.c_size_t * B)(*[c.shape[0] for c in self._staged])
+        self._check(self.lib.qasr_batch_stage(self.h, ptrs, ns, B))
+
+    def batch_begin_staged(self, **opt):
+        o = self._options(**opt)
+        self._check(self.lib.qasr_batch_begin_staged(self.h, C.byref(o)))
+        self._clips = self._staged
+        self._B = len(self._clips)
+
     def batch_rewind(self):
         self._check(self.lib.qasr_batch_rewind(self.h))
 

@@ -27,10 +27,18 @@ class StandInEngine:
     cfg = _Cfg()
 
     def __init__(self, delay):
-        self.delay, self.begun, self.ran = delay, 0, 0
+        self.delay, self.begun, self.ran, self.staged = delay, 0, 0, 0
 
     def batch_begin(self, clips, max_tokens, ignore_eos):
         self.ids = [int(c[0]) for c in clips]
+        self.begun += 1
+
+    def batch_stage(self, clips):                       # the pipelined loop of bench.py: next batch staged under the current one
+        self.staged_ids = [int(c[0]) for c in clips]
+        self.staged += 1
+
+    def batch_begin_staged(self, max_tokens, ignore_eos):
+        self.ids = self.staged_ids
         self.begun += 1
 
     def batch_rewind(self):
@@ -58,10 +66,10 @@ def main():
     clips = [np.array([k], dtype=np.float32) for k in ids]
     eng = StandInEngine(delay=0.05 if rank == 0 else 0.20)          # rank 1 is the slow one: dt must be ITS time on both
     gathered = torch.empty((world * B, S), dtype=torch.int32)
-    dt, lens = qd.timed_passes(eng, clips, N_DEC, steps=2, warmup=1, inclusive=True, gathered=gathered)
+    dt, lens = qd.timed_passes(eng, clips, N_DEC, steps=2, warmup=1, inclusive=True, gathered=gathered, pipelined=True)
     dt_res, _ = qd.timed_passes(eng, clips, N_DEC, steps=1, warmup=0, inclusive=False, gathered=gathered)
     json.dump({"rank": rank, "world": world, "ids": ids, "dt": dt, "dt_res": dt_res, "lens": lens.tolist(),
-               "gathered": gathered.tolist(), "begun": eng.begun, "ran": eng.ran},
+               "gathered": gathered.tolist(), "begun": eng.begun, "ran": eng.ran, "staged": eng.staged},
               open(os.path.join(os.environ["OUT_DIR"], f"rank{rank}.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -125,6 +125,7 @@ def test_bench_sharding_path_under_torchrun(tmp_path):
     for x in res:
         assert x["world"] == 2 and x["gathered"] == expect and x["lens"] == [5, 5, 5]
         assert x["begun"] == 3 + 1 and x["ran"] == 3 + 1            # 1 warm-up + 2 timed inclusive passes, then 1 resident
+        assert x["staged"] == 3                                     # pipelined loop: every pass staged its successor's clips
         assert x["dt"] >= 2 * 0.20 and x["dt"] < 2 * 0.20 + 0.5       # two passes of the SLOW rank, warm-up excluded
     assert abs(res[0]["dt"] - res[1]["dt"]) < 1e-9                    # MAX-reduced: identical on both ranks
     assert abs(res[0]["dt_res"] - res[1]["dt_res"]) < 1e-9 and res[0]["dt_res"] >= 0.20

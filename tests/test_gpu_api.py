@@ -10,7 +10,7 @@ import torch
 from conftest import GOLDEN
 from oracle import config as OC, tokenizer as otok
 from qasr import _lib, synth, config as QC
-from qasr.model import Qwen3ASRModel
+from qasr.model import Qwen3ASRModel, QasrError
 
 pytestmark = pytest.mark.gpu
 KAT = json.load(open(os.path.join(GOLDEN, "kat_reference_tests.json"), encoding="utf-8"))
@@ -420,3 +420,36 @@ def test_streaming_asr_batched_equals_sequential(model):
     assert [s.segment_index for s in seq] == list(range(len(seq)))
     # (after a force-split the closing segment still reports the VAD segment's own start time, as in the reference)
     assert all(seq[i].end_time > seq[i - 1].end_time for i in range(1, len(seq)))
+
+
+def test_staged_batches_equal_plain_batches(sd):
+    """qasr_batch_stage / qasr_batch_begin_staged (the next batch's staging + H2D under the current batch's kernels) give the tokens of
+    qasr_batch_begin for every batch of a sequence with changing sizes and clip lengths; staging before the current batch has started,
+    or adopting without a staged batch, is refused; a plain qasr_batch_begin discards a staged batch."""
+    m = Qwen3ASRModel.from_state_dict(sd, preset="tiny", max_batch=6, max_audio_seconds=4, max_new_tokens=12)
+    try:
+        batches = [[synth.synth_waveform(10 * i + k, 0.4 + 0.3 * ((i + k) % 5)) for k in range(1 + (2 * i) % 6)] for i in range(5)]
+        want = [m.transcribe_batch(b, max_tokens=7, ignore_eos=True) for b in batches]
+        got = []
+        m.batch_begin(batches[0], max_tokens=7, ignore_eos=True)
+        with pytest.raises(QasrError, match="qasr error 1"):
+            m.batch_stage(batches[1])                       # the current batch's log-mel has not been queued yet
+        for i in range(len(batches)):
+            m.batch_run()
+            if i + 1 < len(batches):
+                m.batch_stage(batches[i + 1])
+            toks, lens = m.batch_tokens()
+            got.append([toks[b, :lens[b]].tolist() for b in range(len(batches[i]))])
+            if i + 1 < len(batches):
+                m.batch_begin_staged(max_tokens=7, ignore_eos=True)
+        assert got == want
+        with pytest.raises(QasrError, match="qasr error 1"):
+            m.batch_begin_staged(max_tokens=7)              # nothing staged
+        m.batch_run()
+        m.batch_stage(batches[2])
+        m.batch_tokens()
+        assert m.transcribe_batch(batches[1], max_tokens=7, ignore_eos=True) == want[1]      # plain begin: the staged batch is dropped
+        with pytest.raises(QasrError, match="qasr error 1"):
+            m.batch_begin_staged(max_tokens=7)
+    finally:
+        m.close()
