@@ -303,6 +303,18 @@ def main():
             break
         if traffic is None:
             traffic_note = f"no PMC file under profiles/ matches the current kernel sources ({stamp}); not quoted"
+        gemv_traffic, gemv_traffic_note = None, None
+        gstamp = kernel_source_stamp(GEMV_SOURCES)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            pmc = json.load(open(f))
+            if pmc.get("gemv_source_stamp") != gstamp or not pmc.get("layer_gemv_group_bytes"):
+                continue
+            gemv_traffic = pmc["layer_gemv_group_bytes"]
+            gemv_traffic_note = (f"profiles/{os.path.basename(f)} (kernel sources {gstamp}): (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the four "
+                                 f"launches of a layer, separate --pmc passes of a 16-token run")
+            break
+        if gemv_traffic is None:
+            gemv_traffic_note = f"no PMC file under profiles/ matches the current GEMV kernel sources ({gstamp}); not quoted"
         # which kernel dominates the GPU time of a pass: the decode attention (one launch per layer and step) or the decode-step GEMV
         # kernel (decode_gemv2_kernel, four launches per layer and step: q|k|v, o-proj, gate|up, down).  Shares from the live probes
         # (HIP events on the engine stream; the GEMV probe walks the layers so that every launch streams its weights from HBM as in situ)
@@ -359,8 +371,7 @@ def main():
         if share_gemv > share_attn:
             # the GEMV kernel takes more of the pass than the attention: IT is the dominant kernel and the object's headline figure;
             # the attention (closer to its roofline) is kept beside it, never instead of it
-            out["roofline"] = {"bound": "hbm", **gemv_family, "traffic": None,
-                               "traffic_source": "PMC traffic of this kernel: profiles/ (per-kernel CSV of the round); not re-derived here",
+            out["roofline"] = {"bound": "hbm", **gemv_family, "traffic": gemv_traffic, "traffic_source": gemv_traffic_note,
                                "how": "algorithmic bytes = the bf16 weights of one decoder layer (8.39 + 4.19 + 12.58 + 6.29 MB); duration = HIP events "
                                       "on the engine stream around 20 x 4 launches walking the 28 layers (weights from HBM, as in the step)",
                                "attention": attn_obj, "other": other}

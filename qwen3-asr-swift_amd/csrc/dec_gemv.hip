@@ -382,6 +382,8 @@ static bool gemv2_nb(const DecGemv2Args& a2, hipStream_t s) {
         DecGemv2Args b2 = a2;
         b2.rows_per_group = 16;
         b2.row_groups = nb;
+        const int ew = tuning().gemv_earlyw;          // 2: every GEMV | 3: the residual GEMVs only (A/B at full batches; see EARLYW)
+        if (ew == 2 || (ew == 3 && EPI == DEC_EPI_RESID)) return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, false, true>(b2, s);
         return gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI>(b2, s);
     }
     // all batch rows resident in LDS when they fit (LDS and staging registers), else 16 rows per phase
@@ -389,7 +391,7 @@ static bool gemv2_nb(const DecGemv2Args& a2, hipStream_t s) {
     switch (nb) {
         case 1:
             if constexpr (EPI != DEC_EPI_LOGITS) {
-                const bool earlyw = a2.g.B <= 8 && tuning().gemv_earlyw;
+                const bool earlyw = (a2.g.B <= 8 && tuning().gemv_earlyw == 1) || tuning().gemv_earlyw == 2;
                 if constexpr (PRO == DEC_PRO_RMSNORM) {
                     if (a2.g.B < 16 && tuning().gemv_partial)
                         return earlyw ? gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, true, true>(a2, s) : gemv2_go<NT, 1, WAVES, KSW, true, PRO, EPI, true>(a2, s);

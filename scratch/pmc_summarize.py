@@ -42,7 +42,7 @@ sys.path.insert(0, root)
 import bench                                    # kernel_source_stamp(): the traffic figure is tied to the kernels it was measured on
 gemv = sum(r[4] * r[1] for r in rows if "decode_gemv2_kernel" in r[0])
 n_layers_steps = n_att
-out = {"kernel_source_stamp": bench.kernel_source_stamp(), "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 --decode-tokens 16 "
+out = {"kernel_source_stamp": bench.kernel_source_stamp(), "gemv_source_stamp": bench.kernel_source_stamp(bench.GEMV_SOURCES), "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 --decode-tokens 16 "
                  "--no-cpu-baseline --no-extras`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
        "decode_attention_bytes": att, "decode_attention_launches": n_att,
        "layer_gemv_group_bytes": gemv / n_att if n_att else None, "lm_head_bytes": lm,
