@@ -31,7 +31,7 @@ __device__ __forceinline__ long vfrag_index(int key, int d) {
 // loads return in order, so in the other order the query math waits behind the whole K / V stream of its wave: in-kernel stamps at 1 clip
 // put "query ready" 5.2 us after the first wave's start (ctx_len round trip -> K / V from HBM -> q rows), with the sweep itself 0.85 us.
 // Same arithmetic either way (bit-identical results).
-template <int HD, int WAVES, int UNR, bool SPEC, bool EARLYQ>
+template <int HD, int WAVES, int UNR, int SPEC, bool EARLYQ>
 __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     const bf16_t* __restrict__ qkv, const int* __restrict__ ctx_len, int heads, int kv_heads,
     const bf16_t* __restrict__ qn_w, const bf16_t* __restrict__ kn_w, float eps, const float* __restrict__ rope_cos,
@@ -55,9 +55,10 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
     const bf16_t* vfb = cache.vf + cache.off(b, kvh, 0) + lane * 8;
     const int max_chunk = cache.max_ctx / 32 - 1;
     uint4 kreg[UNR][2 * KS], vreg[UNR][DT];
-    auto issue = [&](int chunk0, int limit) {
+    auto issue = [&](int chunk0, int limit, int u_lo = 0, int u_hi = UNR) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
+            if (u < u_lo || u >= u_hi) continue;
             int ch = chunk0 + u * WAVES;
             if (ch >= limit) continue;                                   // wave-uniform: no bytes for chunks past the context
             ch = ch < max_chunk ? ch : max_chunk;                        // clamped to the allocation, masked later
@@ -111,8 +112,15 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
         __builtin_amdgcn_sched_barrier(0);   // keep these requests ahead of the K / V stream (in-order return)
     }
     int pos;
-    if (SPEC) {
-        issue(wave, 0x7fffffff);             // before the position is known: rows past it are masked
+    if (SPEC == 1) {
+        // the wave's FIRST chunk before the position is known (rows past it are masked): with WAVES x 32 keys in the first round every
+        // context of 256+ keys makes all of these requests useful; the later chunks wait for ctx_len, so no byte is fetched for chunks past
+        // the context (requesting all of them blind fetched 1.26 x the algorithmic bytes at 32 x 30 s: profiles/r03_v2_pmc_traffic.json)
+        issue(wave, 0x7fffffff, 0, 1);
+        pos = ctx_len[b];
+        issue(wave, (pos + 31) >> 5, 1, UNR);
+    } else if (SPEC == 2) {
+        issue(wave, 0x7fffffff);             // every chunk of the first round blind: latency-bound launches (few batch rows) only
         pos = ctx_len[b];
     } else {
         pos = ctx_len[b];
@@ -302,21 +310,20 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     const int nw = tuning().da_waves;
     // da_spec: 0 never | 1 always | 2 auto: only while the launch is latency-bound (few batch rows: the wasted bytes of chunks past the
     // context cost nothing there, and the K / V round trip no longer waits for the ctx_len round trip)
+    // da_spec: 0 never | 1 the first chunk of every wave | 2 every chunk of the first round | 3 (default) 2 up to 8 batch rows (the launch is
+    // latency-bound there and the bytes of chunks past the context cost nothing), 1 above
     const int spec_knob = tuning().da_spec;
-    const bool spec = spec_knob == 1 || (spec_knob == 2 && B <= 8);
+    const int spec = spec_knob == 3 ? (B <= 8 ? 2 : 1) : spec_knob;
     const bool early = tuning().da_earlyq != 0;
 #define QASR_DAM_GO(HD_, W_, U_, S_, E_)                                                                                         \
     hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_, E_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, kv_heads, \
                        qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg)
     if (hd == 128) {
-        if (nw == 16 && spec) QASR_DAM_GO(128, 16, 1, true, true);
-        else if (nw == 16) QASR_DAM_GO(128, 16, 1, false, true);
-        else if (spec && early) QASR_DAM_GO(128, 8, 2, true, true);
-        else if (spec) QASR_DAM_GO(128, 8, 2, true, false);
-        else if (early) QASR_DAM_GO(128, 8, 2, false, true);
-        else QASR_DAM_GO(128, 8, 2, false, false);
+        if (nw == 16) { if (spec) QASR_DAM_GO(128, 16, 1, 2, true); else QASR_DAM_GO(128, 16, 1, 0, true); }
+        else if (early) { if (spec == 2) QASR_DAM_GO(128, 8, 2, 2, true); else if (spec == 1) QASR_DAM_GO(128, 8, 2, 1, true); else QASR_DAM_GO(128, 8, 2, 0, true); }
+        else { if (spec == 2) QASR_DAM_GO(128, 8, 2, 2, false); else if (spec == 1) QASR_DAM_GO(128, 8, 2, 1, false); else QASR_DAM_GO(128, 8, 2, 0, false); }
     } else if (hd == 32) {
-        QASR_DAM_GO(32, 8, 1, false, true);
+        QASR_DAM_GO(32, 8, 1, 0, true);
     } else
         throw std::invalid_argument("decode attention: unsupported head_dim");
 #undef QASR_DAM_GO

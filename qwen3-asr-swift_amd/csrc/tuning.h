@@ -15,8 +15,9 @@ struct Tuning {
     int gemv_earlyw = 1;     // at most 8 batch rows: the weight stream requested without waiting for the activation rows | 0 after them (as at 16+ rows)
     int gemv_wide = 1;       // K = 6144 (1.7B down-projection): 1 two-phase LDS image, weights in registers (dec_gemv_wide.hip) | 0 generic kernel
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
-    int da_spec = 1;         // first K/V loads issued before ctx_len is known: 1 always (round 3: -2 % decode at 1 / 8 clips, 0 ... -1.6 % at 32) |
-                             // 0 never | 2 up to 8 batch rows only
+    int da_spec = 3;         // K/V requests issued before ctx_len is known: 0 none | 1 each wave's first chunk (no byte past the context at 256+ keys) |
+                             // 2 every chunk of the first round (1.26 x the algorithmic bytes at 32 x 30 s) | 3 = 2 up to 8 batch rows, 1 above
+                             // (round 3: decode -2 % at 1 / 8 clips, -0.7 % at 32)
     int da_earlyq = 0;       // 1: the token's own q / k / v rows requested ahead of the K / V stream (loads return in order; +-0, measured) | 0 after it
     int pa_form = 2;         // prompt attention: 2 transposed-score form | 1 first form (a third, 32x32x16 form was measured and dropped:
                              // profiles/r02_ab_prompt_attention_form3.txt)
