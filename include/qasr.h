@@ -185,7 +185,8 @@ int qasr_batch_run(qasr_engine* e);                     /* mel + encoder + prefi
  * qasr_batch_stage copies the NEXT batch's clips into a second pinned buffer and queues their host -> HBM copy on a copy stream behind
  * the current batch's log-mel (the only reader of the device PCM buffer), so that staging + PCIe run under the current batch's encoder /
  * prompt pass / decode.  Call it after qasr_batch_run of the current batch (QASR_ERR_INVALID before that); qasr_batch_begin_staged then
- * adopts the staged batch (planning only) once the current batch's tokens have been read.  Same results as qasr_batch_begin. */
+ * adopts the staged batch (planning only) once the current batch's tokens have been read.  Same results as qasr_batch_begin.  Once its
+ * successor is staged a batch cannot be run again (qasr_batch_rewind + qasr_batch_run: QASR_ERR_INVALID): its samples have left the device. */
 int qasr_batch_stage(qasr_engine* e, const float* const* pcm, const size_t* n, size_t B);
 int qasr_batch_begin_staged(qasr_engine* e, const qasr_options* opt);
 /* Re-arm the resident batch (PCM + plans stay in HBM, greedy state is reset on the device) so that

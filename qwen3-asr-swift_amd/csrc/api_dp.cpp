@@ -9,6 +9,7 @@
 // use for a device-side all-gather; the multi-process form of the same partition, with the RCCL all_gather of that block, is bench.py).
 #include "engine.h"
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>

@@ -842,6 +842,7 @@ void Engine::batch_begin_staged(const qasr_options* opt) {
     batch_max_frames_all_ = staged_max_frames_all_;
     staged_valid_ = false;
     run_issued_ = false;
+    pcm_staged_over_ = false;
     d_pcm_off_ = d_meta_.as<long>();
     d_n_samples_ = reinterpret_cast<int*>(d_pcm_off_ + batch_);
     d_frame_off_ = d_n_samples_ + batch_;
@@ -851,6 +852,9 @@ void Engine::batch_begin_staged(const qasr_options* opt) {
 
 void Engine::batch_run() {
     require_batch("batch_run");
+    if (pcm_staged_over_)
+        throw std::invalid_argument("batch_run: qasr_batch_stage has replaced this batch's samples in the device PCM buffer; a batch cannot be run "
+                                    "again (qasr_batch_rewind) once its successor is staged");
     hipStream_t s = stream_;
     QASR_HIP(hipEventRecord(ev_[0], s));
     run_mel();

@@ -188,7 +188,7 @@ private:
     hipEvent_t ev_mel_done_ = nullptr, ev_stage_done_ = nullptr;
     std::vector<ClipPlan> staged_clips_;
     int staged_B_ = 0, staged_max_frames_all_ = 0;
-    bool staged_valid_ = false, run_issued_ = false;
+    bool staged_valid_ = false, run_issued_ = false, pcm_staged_over_ = false;
     void stage_pcm(const float* const* pcm, const size_t* n, size_t B, HostBuf& hp, HostBuf& hm, hipStream_t cs, std::vector<ClipPlan>& clips,
                    int& max_frames_all);
     DevBuf d_pcm_, d_meta_, d_mel_raw_, d_gmax_, d_mel_;

@@ -200,6 +200,7 @@ void Engine::upload_pcm(const float* const* pcm, const size_t* n, size_t B) {
     stage_pcm(pcm, n, B, h_pcm_, h_meta_, stream_, clips_, batch_max_frames_all_);
     batch_ = (int)B;
     run_issued_ = false;
+    pcm_staged_over_ = false;
     d_pcm_off_ = d_meta_.as<long>();
     d_n_samples_ = reinterpret_cast<int*>(d_pcm_off_ + B);
     d_frame_off_ = d_n_samples_ + B;
@@ -227,6 +228,7 @@ void Engine::batch_stage(const float* const* pcm, const size_t* n, size_t B) {
     QASR_HIP(hipEventRecord(ev_stage_done_, copy_stream_));
     staged_B_ = (int)B;
     staged_valid_ = true;
+    pcm_staged_over_ = true;                       // the device PCM buffer no longer holds the current batch
 }
 void Engine::run_mel() {
     MelBatch mb;

@@ -448,6 +448,9 @@ def test_staged_batches_equal_plain_batches(sd):
         m.batch_run()
         m.batch_stage(batches[2])
         m.batch_tokens()
+        m.batch_rewind()
+        with pytest.raises(QasrError, match="qasr error 1"):
+            m.batch_run()                                   # the staged batch's samples replaced this batch's in the device buffer
         assert m.transcribe_batch(batches[1], max_tokens=7, ignore_eos=True) == want[1]      # plain begin: the staged batch is dropped
         with pytest.raises(QasrError, match="qasr error 1"):
             m.batch_begin_staged(max_tokens=7)
