@@ -16,9 +16,21 @@
 #include <thread>
 #include <vector>
 
+// One whole batch in flight on one engine (qasr_dp_submit / qasr_dp_collect): the engine's host thread, the result block it fills and
+// the status it ends with.  The caller's PCM buffers are read by that thread until the ticket is collected.
+struct Lane {
+    std::thread worker;
+    int64_t ticket = -1;                  // -1: idle
+    size_t B = 0;
+    int rc = QASR_OK;
+    std::vector<int32_t> tokens, lens;
+};
+
 struct qasr_dp {
     std::vector<qasr_engine*> engines;
     std::vector<float> last_ms;           // wall time of each engine's share of the last call
+    std::vector<Lane> lanes;              // one per engine
+    int64_t next_ticket = 0;
     std::string last_error;
 };
 
@@ -50,12 +62,15 @@ int qasr_dp_create(const char* model_dir, const qasr_config* cfg, const int32_t*
         dp->engines.push_back(e);
     }
     dp->last_ms.assign((size_t)n_devices, 0.f);
+    dp->lanes.resize((size_t)n_devices);
     *out = dp.release();
     return QASR_OK;
 }
 
 void qasr_dp_destroy(qasr_dp* dp) {
     if (!dp) return;
+    for (Lane& l : dp->lanes)
+        if (l.worker.joinable()) l.worker.join();          // a batch still in flight finishes before its engine goes away
     for (qasr_engine* e : dp->engines) qasr_destroy(e);
     delete dp;
 }
@@ -94,6 +109,11 @@ int qasr_dp_transcribe_batch(qasr_dp* dp, const float* const* pcm, const size_t*
     if (!dp || dp->engines.empty() || (B && (!pcm || !n || !tokens || !lens))) return QASR_ERR_INVALID;
     if (B == 0) return QASR_OK;
     const size_t G = dp->engines.size();
+    for (size_t g = 0; g < G; ++g)
+        if (dp->lanes[g].ticket >= 0) {
+            dp->last_error = "engine " + std::to_string(g) + " holds ticket " + std::to_string(dp->lanes[g].ticket) + ": collect it first";
+            return QASR_ERR_INVALID;
+        }
     std::vector<int> rc(G, QASR_OK);
     std::vector<std::thread> pool;
     auto work = [&](size_t g) {
@@ -125,6 +145,71 @@ int qasr_dp_transcribe_batch(qasr_dp* dp, const float* const* pcm, const size_t*
                              "): " + qasr_last_error(dp->engines[g]);
             return rc[g];
         }
+    return QASR_OK;
+}
+
+// ---- whole batches in flight, one per engine ------------------------------------------------------------------------------------
+// The decode stage of a pass is bound by the latency of its 142 dependent launches per token, not by bytes or flops: a
+// second pass on the same GPU, on its own streams, runs in the gaps.  Engines listed on the same device are such lanes; batch k goes to
+// engine k % n whole (one pass = one batch, as in the reference's loop, TranscribeBatchCommand.swift:82-93), so n passes are in flight.
+int qasr_dp_submit(qasr_dp* dp, const float* const* pcm, const size_t* n, size_t B, int sample_rate, const qasr_options* opt,
+                   int64_t* ticket) {
+    if (!dp || dp->engines.empty() || !ticket || (B && (!pcm || !n))) return QASR_ERR_INVALID;
+    const size_t g = (size_t)(dp->next_ticket % (int64_t)dp->engines.size());
+    Lane& l = dp->lanes[g];
+    if (l.ticket >= 0) {
+        dp->last_error = "engine " + std::to_string(g) + " still holds ticket " + std::to_string(l.ticket) + ": collect it before the next submit";
+        return QASR_ERR_INVALID;
+    }
+    qasr_engine* e = dp->engines[g];
+    const qasr_config& c = e->impl->config();
+    const size_t stride = (size_t)c.max_new_tokens + 1, cap = (size_t)c.max_batch;
+    try {
+        l.tokens.assign(B * stride, -1);
+        l.lens.assign(B, 0);
+        l.B = B;
+        l.rc = QASR_OK;
+        const qasr_options o = opt ? *opt : qasr_options{};
+        const bool has_opt = opt != nullptr;
+        l.worker = std::thread([dp, g, e, pcm, n, B, sample_rate, o, has_opt, stride, cap]() {
+            Lane& l = dp->lanes[g];
+            const auto t0 = std::chrono::steady_clock::now();
+            for (size_t b0 = 0; b0 < B && l.rc == QASR_OK; b0 += cap) {
+                const size_t nb = std::min(cap, B - b0);
+                l.rc = qasr_transcribe_batch(e, pcm + b0, n + b0, nb, sample_rate, has_opt ? &o : nullptr, l.tokens.data() + b0 * stride,
+                                             l.lens.data() + b0);
+            }
+            dp->last_ms[g] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+    } catch (const std::exception& ex) {
+        dp->last_error = std::string("cannot start the engine's host thread: ") + ex.what();
+        return QASR_ERR_INVALID;
+    }
+    l.ticket = dp->next_ticket++;
+    *ticket = l.ticket;
+    return QASR_OK;
+}
+
+int qasr_dp_collect(qasr_dp* dp, int64_t ticket, int32_t* tokens, int32_t* lens) {
+    if (!dp || dp->engines.empty() || ticket < 0) return QASR_ERR_INVALID;
+    const size_t g = (size_t)(ticket % (int64_t)dp->engines.size());
+    Lane& l = dp->lanes[g];
+    if (l.ticket != ticket) {
+        dp->last_error = "ticket " + std::to_string(ticket) + " is not in flight (already collected, or never issued)";
+        return QASR_ERR_INVALID;
+    }
+    if (l.B && (!tokens || !lens)) return QASR_ERR_INVALID;      // the batch stays in flight: call again with buffers
+    l.worker.join();
+    l.ticket = -1;
+    if (l.rc != QASR_OK) {
+        dp->last_error = "engine " + std::to_string(g) + " (device " + std::to_string(dp->engines[g]->impl->config().device) + "): " +
+                         qasr_last_error(dp->engines[g]);
+        return l.rc;
+    }
+    if (l.B) {
+        std::memcpy(tokens, l.tokens.data(), l.tokens.size() * sizeof(int32_t));
+        std::memcpy(lens, l.lens.data(), l.lens.size() * sizeof(int32_t));
+    }
     return QASR_OK;
 }
 

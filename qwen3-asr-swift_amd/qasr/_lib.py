@@ -159,6 +159,8 @@ SIGNATURES = {
     "qasr_dp_finalize": (C.c_int, [_E]),
     "qasr_dp_transcribe_batch": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(QasrOptions), _I, _I]),
     "qasr_dp_timings": (C.c_int, [_E, _F, C.c_int32]),
+    "qasr_dp_submit": (C.c_int, [_E, _P(_F), _P(C.c_size_t), C.c_size_t, C.c_int, _P(QasrOptions), _P(C.c_int64)]),
+    "qasr_dp_collect": (C.c_int, [_E, C.c_int64, _I, _I]),
     "qasr_nemo_mel_create": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_float, _P(_E)]),
     "qasr_nemo_mel_destroy": (None, [_E]),
     "qasr_nemo_mel_last_error": (C.c_char_p, [_E]),

@@ -24,6 +24,7 @@ class Qwen3ASRDataParallel:
         if rc != 0:
             raise QasrError(f"qasr_dp_create failed ({rc}): {self.lib.qasr_dp_last_error(None).decode()}")
         self.n_devices = self.lib.qasr_dp_n_devices(self.h)
+        self._in_flight = {}                  # ticket -> (arrays the engine's thread still reads, B)
 
     @classmethod
     def from_state_dict(cls, sd, devices, preset="0.6B", **capacity):
@@ -43,8 +44,9 @@ class Qwen3ASRDataParallel:
 
     def close(self):
         if self.h:
-            self.lib.qasr_dp_destroy(self.h)
+            self.lib.qasr_dp_destroy(self.h)          # waits for batches still in flight
             self.h = None
+            self._in_flight.clear()
 
     def transcribe_batch(self, clips, sample_rate=16000, **opt):
         """-> token id lists, clip order preserved.  Options as Qwen3ASRModel.transcribe_batch."""
@@ -58,6 +60,30 @@ class Qwen3ASRDataParallel:
         o = Qwen3ASRModel._options(self, **opt)
         self._check(self.lib.qasr_dp_transcribe_batch(self.h, ptrs, ns, B, int(sample_rate), C.byref(o), _iptr(toks), _iptr(lens)))
         return [toks[b, :lens[b]].tolist() for b in range(B)]
+
+    def submit(self, clips, sample_rate=16000, **opt):
+        """One whole batch to the next engine (round robin), without waiting: -> ticket for collect().  With a device listed twice the
+        GPU keeps two passes in flight (qasr_dp_submit)."""
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        B = len(clips)
+        ptrs = (C.POINTER(C.c_float) * B)(*[_fptr(c) for c in clips])
+        ns = (C.c_size_t * B)(*[c.shape[0] for c in clips])
+        o = Qwen3ASRModel._options(self, **opt)
+        t = C.c_int64(-1)
+        self._check(self.lib.qasr_dp_submit(self.h, ptrs, ns, B, int(sample_rate), C.byref(o), C.byref(t)))
+        self._in_flight[t.value] = (clips, ptrs, ns, B)
+        return t.value
+
+    def collect(self, ticket, raw=False):
+        """Waits for that batch: -> token id lists (raw: the [B, max_new_tokens + 1] block and the lens)."""
+        B = self._in_flight[ticket][3] if ticket in self._in_flight else 0
+        toks = np.full((B, self.cfg.max_new_tokens + 1), -1, dtype=np.int32)
+        lens = np.zeros(B, dtype=np.int32)
+        try:
+            self._check(self.lib.qasr_dp_collect(self.h, int(ticket), _iptr(toks), _iptr(lens)))
+        finally:
+            self._in_flight.pop(ticket, None)
+        return (toks, lens) if raw else [toks[b, :lens[b]].tolist() for b in range(B)]
 
     def timings(self):
         ms = (C.c_float * self.n_devices)()

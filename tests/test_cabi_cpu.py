@@ -231,4 +231,6 @@ def test_dp_argument_checks_without_a_gpu():
     assert lib.qasr_dp_n_devices(None) == 0 and lib.qasr_dp_engine(None, 0) is None
     assert lib.qasr_dp_transcribe_batch(None, None, None, 0, 16000, None, None, None) != 0
     assert lib.qasr_dp_finalize(None) != 0 and lib.qasr_dp_set_tensor(None, b"x", None, 0, None, 0) != 0
+    t = C.c_int64(-1)
+    assert lib.qasr_dp_submit(None, None, None, 0, 16000, None, C.byref(t)) != 0 and lib.qasr_dp_collect(None, 0, None, None) != 0
     lib.qasr_dp_destroy(None)

@@ -45,6 +45,44 @@ def test_dp_equals_single_engine(sd, single, devices):
         dp.close()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]], ids=["n1", "n2-shared", "n3-shared"])
+def test_batches_in_flight_equal_single_engine(sd, single, devices):
+    """qasr_dp_submit / qasr_dp_collect: batch k whole on engine k % n, n passes in flight on the GPU, tokens identical to one engine's."""
+    dp = Qwen3ASRDataParallel.from_state_dict(sd, devices, preset="tiny", max_batch=4, max_audio_seconds=4, max_new_tokens=12)
+    try:
+        n = len(devices)
+        batches = [_clips(B)[k % 3:] for k, B in enumerate((4, 7, 3, 9, 4, 5, 2))]      # ragged, some beyond an engine's capacity (4)
+        want = [single.transcribe_batch(c, max_tokens=9) for c in batches]
+        got, pending = {}, []
+        for k, c in enumerate(batches):                                                 # the serving loop: collect the oldest, submit the next
+            if len(pending) == n:
+                t0, k0 = pending.pop(0)
+                got[k0] = dp.collect(t0)
+            pending.append((dp.submit(c, max_tokens=9), k))
+        with pytest.raises(QasrError, match="collect it first"):                        # the one-batch-over-all-engines form refuses meanwhile
+            dp.transcribe_batch(batches[0], max_tokens=9)
+        if n == 1:
+            with pytest.raises(QasrError, match="still holds ticket"):
+                dp.submit(batches[0], max_tokens=9)
+        for t, k in reversed(pending):                                                  # any collection order
+            got[k] = dp.collect(t)
+        assert [got[k] for k in range(len(batches))] == want
+        with pytest.raises(QasrError, match="not in flight"):
+            dp.collect(pending[0][0])
+        t = dp.submit([], max_tokens=9)                                                 # an empty batch is a ticket like any other
+        assert dp.collect(t) == []
+        assert dp.transcribe_batch(batches[1], max_tokens=9) == want[1]                 # and the synchronous form works again
+    finally:
+        dp.close()
+
+
+def test_destroy_with_a_batch_in_flight(sd):
+    dp = Qwen3ASRDataParallel.from_state_dict(sd, [0, 0], preset="tiny", max_batch=4, max_audio_seconds=4, max_new_tokens=12)
+    clips = _clips(4)
+    dp.submit(clips, max_tokens=9)
+    dp.close()                                                                          # waits for the engine's thread, then frees
+
+
 def test_dp_errors(sd):
     lib = _lib.load(strict=True)
     with pytest.raises(QasrError):
