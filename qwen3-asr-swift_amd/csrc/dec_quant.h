@@ -41,6 +41,21 @@ void quant_pack_launch(const QuantRaw& src, uint32_t* qp, void* sb, hipStream_t 
 void quant_dequant_rows_launch(const QuantRaw& src, int r0, int nrows, bf16_t* out, hipStream_t s, int block = 0, int block_stride = 0,
                                int block_off = 0);
 
+// the same for up to eight matrices in one launch (block == 0: rows back to back)
+struct DequantJob {
+    QuantRaw q;
+    int r0 = 0, nrows = 0;
+    bf16_t* out = nullptr;
+    int block = 0, block_stride = 0, block_off = 0;
+};
+struct DequantJobs {
+    enum { MAX = 8 };
+    DequantJob job[MAX];
+    int first_block[MAX];
+    int n;
+};
+void quant_dequant_multi_launch(const DequantJob* jobs, int n, hipStream_t s);
+
 // x[p] = audio_src[p] >= 0 ? audio[audio_src[p]] : dequantized(embed row ids[p])      (Qwen3ASR.swift:236-244)
 void embed_splice_q_launch(const int* ids, const int* audio_src, const QuantRaw& embed, const bf16_t* audio, bf16_t* x,
                            int n_pos, int H, hipStream_t s);

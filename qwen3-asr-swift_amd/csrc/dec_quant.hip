@@ -154,6 +154,49 @@ void quant_dequant_rows_launch(const QuantRaw& src, int r0, int nrows, bf16_t* o
     hipLaunchKernelGGL(quant_dequant_rows_kernel, dim3(nrows), dim3(128), 0, s, src, r0, out, block, block_stride, block_off);
 }
 
+// Several matrices in ONE launch (a decoder layer's seven for the prompt pass: seven launches of row-sized workgroups cost 46 us per layer,
+// four times the time the 40 MB they move need).  A workgroup works inside one matrix (the job index is wave-uniform: its descriptor
+// comes through scalar loads from the kernel arguments), 256 threads x 4 chunks of 8 elements.
+__global__ __launch_bounds__(256) void quant_dequant_multi_kernel(DequantJobs J) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < DequantJobs::MAX; ++i) k += (i < J.n && (int)blockIdx.x >= J.first_block[i]) ? 1 : 0;
+    k = __builtin_amdgcn_readfirstlane(k);
+    const DequantJob jb = J.job[k];
+    const int cpr = jb.q.K / 8;
+    const long total = (long)jb.nrows * cpr;
+    const long base = ((long)blockIdx.x - J.first_block[k]) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long c = base + u * 256;
+        if (c < total) {
+            const long row = c / cpr;
+            const int cc = (int)(c - row * cpr);
+            const long orow = (row / jb.block) * jb.block_stride + jb.block_off + row % jb.block;
+            reinterpret_cast<uint4*>(jb.out + orow * jb.q.K)[cc] = quant_dequant_chunk(jb.q, jb.r0 + row, cc);
+        }
+    }
+}
+
+void quant_dequant_multi_launch(const DequantJob* jobs, int n, hipStream_t s) {
+    if (n <= 0) return;
+    if (n > DequantJobs::MAX) throw std::invalid_argument("quant_dequant_multi_launch: too many matrices for one launch");
+    DequantJobs J{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        DequantJob jb = jobs[i];
+        if (jb.q.K % 64 != 0) throw std::invalid_argument("quantised matrix: K must be a multiple of the group size 64");
+        if (jb.nrows < 0) throw std::invalid_argument("quant_dequant_multi_launch: negative row count");
+        if (jb.block <= 0) { jb.block = jb.nrows > 0 ? jb.nrows : 1; jb.block_stride = 0; jb.block_off = 0; }
+        J.job[i] = jb;
+        J.first_block[i] = blocks;
+        blocks += (int)cdiv((long)jb.nrows * (jb.q.K / 8), 1024);
+    }
+    J.n = n;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(quant_dequant_multi_kernel, dim3(blocks), dim3(256), 0, s, J);
+}
+
 __global__ void embed_splice_q_kernel(const int* __restrict__ ids, const int* __restrict__ audio_src, QuantRaw q,
                                       const bf16_t* __restrict__ audio, bf16_t* __restrict__ x, int H) {
     const int p = blockIdx.x, a = audio_src ? audio_src[p] : -1;

@@ -294,13 +294,6 @@ void Engine::finalize_decoder() {
     gstate_.vocab = cfg_.vocab;
     for (auto& e : ev_)
         if (!e) QASR_HIP(hipEventCreate(&e));
-    if (!fork_ev_) {
-        QASR_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
-        for (int i = 0; i < 3; ++i) {
-            QASR_HIP(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
-            QASR_HIP(hipEventCreateWithFlags(&join_ev_[i], hipEventDisableTiming));
-        }
-    }
     QASR_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -424,13 +417,14 @@ Engine::PromptW Engine::prompt_weights(int l, hipStream_t s) {
     bf16_t* wo = wqkv + (size_t)(nq + 2 * nkv) * H;
     bf16_t* wgu = wo + (size_t)H * nq;
     bf16_t* wdown = wgu + (size_t)2 * I * H;
-    quant_dequant_rows_launch(L.rq, 0, nq, wqkv, s);
-    quant_dequant_rows_launch(L.rk, 0, nkv, wqkv + (size_t)nq * H, s);
-    quant_dequant_rows_launch(L.rv, 0, nkv, wqkv + (size_t)(nq + nkv) * H, s);
-    quant_dequant_rows_launch(L.ro, 0, H, wo, s);
-    quant_dequant_rows_launch(L.rg, 0, I, wgu, s, 16, 32, 0);       // gate | up in 32-row blocks: 16 gate rows + the 16 matching up rows
-    quant_dequant_rows_launch(L.ru, 0, I, wgu, s, 16, 32, 16);
-    quant_dequant_rows_launch(L.rd, 0, H, wdown, s);
+    const DequantJob jobs[7] = {{L.rq, 0, nq, wqkv},
+                                {L.rk, 0, nkv, wqkv + (size_t)nq * H},
+                                {L.rv, 0, nkv, wqkv + (size_t)(nq + nkv) * H},
+                                {L.ro, 0, H, wo},
+                                {L.rg, 0, I, wgu, 16, 32, 0},       // gate | up in 32-row blocks: 16 gate rows + the 16 matching up rows
+                                {L.ru, 0, I, wgu, 16, 32, 16},
+                                {L.rd, 0, H, wdown}};
+    quant_dequant_multi_launch(jobs, 7, s);                          // one launch per layer
     return {wqkv, wo, wgu, wdown};
 }
 
@@ -674,6 +668,15 @@ void Engine::decode_loop() {
     const int max_steps = cur_max_tokens_ - 1;
     if (max_steps <= 0) return;
     const int split = decode_split_env();
+    if (split > 1 && !fork_ev_) {
+        // side streams only for the row-group A/B knob (decode_split > 1), made before any capture starts: an engine that never splits
+        // owns one compute stream, so that engines sharing a GPU (qasr_dp_submit) each get a hardware queue of their own
+        QASR_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) {
+            QASR_HIP(hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking));
+            QASR_HIP(hipEventCreateWithFlags(&join_ev_[i], hipEventDisableTiming));
+        }
+    }
     // sampled: the slow path's step (logits of every row, pickNextToken, bookkeeping) entirely on the device; the options are kernel
     // arguments of the captured step, so they are part of the graph key
     const bool sampled = slow_path_;
