@@ -258,7 +258,7 @@ def main():
     ap.add_argument("--decode-tokens", type=int, default=128)
     ap.add_argument("--bits", type=int, default=16, choices=[16, 8, 4],
                     help="weights of the HEADLINE engine: 16 = bf16 (BASELINE's config), 4 / 8 = MLX-quantised decoder")
-    ap.add_argument("--lanes", type=int, default=2, help="passes in flight on the GPU in the side leg `passes_in_flight` (qasr_dp_submit)")
+    ap.add_argument("--lanes", type=int, default=3, help="passes in flight on the GPU in the side leg `passes_in_flight` (qasr_dp_submit; 1: 5650, 2: 7440, 3: 7880, 4: 7260 audio-s/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the b=1 / b=8, MLX-4bit and Omnilingual legs (profiling runs)")
     ap.add_argument("--omnilingual", default="300M,7B", help="comma-separated Omnilingual-ASR-CTC variants for the configs[3] legs ('' = none)")

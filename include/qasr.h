@@ -236,10 +236,11 @@ int qasr_dp_timings(const qasr_dp* dp, float* ms_per_engine, int32_t cap);    /*
  * TranscribeBatchCommand.swift:82-93, without its "one after the other"); submit returns at once with a ticket, collect waits for that
  * batch and copies tokens [B, max_new_tokens + 1] / lens [B] out.  List a device twice in qasr_dp_create to keep two passes in flight on
  * one GPU: the decode stage is bound by launch latency, so the second pass runs in the first one's gaps (+30 % audio-seconds/sec at
- * 32 x 30 s on one MI355X).  The pcm / n arrays and the samples must stay valid until the ticket is collected.  At most one
- * uncollected ticket per engine: a submit whose engine still holds one, a collect of a ticket that is not in flight, and
- * qasr_dp_transcribe_batch while any ticket is in flight return QASR_ERR_INVALID.  Tokens are identical to qasr_transcribe_batch's.
- * submit / collect / destroy are for ONE caller thread (the engines' host threads are the library's own). */
+ * 32 x 30 s on one MI355X).  The pcm / n arrays, the samples and the id arrays *opt points to must stay valid until the
+ * ticket is collected (*opt itself is copied).  At most one uncollected ticket per engine: a submit whose engine still holds one, a
+ * collect of a ticket that is not in flight, and qasr_dp_transcribe_batch while any ticket is in flight return QASR_ERR_INVALID.
+ * Tokens are identical to qasr_transcribe_batch's.  submit / collect / destroy are for ONE caller thread (the engines' host threads
+ * are the library's own). */
 int qasr_dp_submit(qasr_dp* dp, const float* const* pcm, const size_t* n, size_t B, int sample_rate, const qasr_options* opt, int64_t* ticket);
 int qasr_dp_collect(qasr_dp* dp, int64_t ticket, int32_t* tokens, int32_t* lens);
 

@@ -24,7 +24,8 @@ class Qwen3ASRDataParallel:
         if rc != 0:
             raise QasrError(f"qasr_dp_create failed ({rc}): {self.lib.qasr_dp_last_error(None).decode()}")
         self.n_devices = self.lib.qasr_dp_n_devices(self.h)
-        self._in_flight = {}                  # ticket -> (arrays the engine's thread still reads, B)
+        self._in_flight = {}                  # ticket -> (clips, pointer arrays, lengths, B, options, option arrays)
+        self._keep = []
 
     @classmethod
     def from_state_dict(cls, sd, devices, preset="0.6B", **capacity):
@@ -37,6 +38,17 @@ class Qwen3ASRDataParallel:
             m._check(m.lib.qasr_dp_set_tensor(m.h, name.encode(), C.c_void_p(t.data_ptr()), codes[t.dtype], shape, t.dim()))
         m._check(m.lib.qasr_dp_finalize(m.h))
         return m
+
+    @classmethod
+    def from_pretrained(cls, model_dir, devices, model_id=None, **capacity):
+        return cls(devices, preset=model_id or model_dir, model_dir=model_dir, **capacity)
+
+    def engine(self, i=0):
+        """Engine i as a Qwen3ASRModel view (tokenizer, single-clip calls, stage entry points); owned by this object."""
+        h = self.lib.qasr_dp_engine(self.h, int(i))
+        if not h:
+            raise QasrError(f"no engine {i}")
+        return Qwen3ASRModel.borrowed(h, self.cfg)
 
     def _check(self, rc):
         if rc != 0:
@@ -71,7 +83,8 @@ class Qwen3ASRDataParallel:
         o = Qwen3ASRModel._options(self, **opt)
         t = C.c_int64(-1)
         self._check(self.lib.qasr_dp_submit(self.h, ptrs, ns, B, int(sample_rate), C.byref(o), C.byref(t)))
-        self._in_flight[t.value] = (clips, ptrs, ns, B)
+        self._in_flight[t.value] = (clips, ptrs, ns, B, o, self._keep)      # all of it is read by the engine's thread until collect()
+        self._keep = []
         return t.value
 
     def collect(self, ticket, raw=False):

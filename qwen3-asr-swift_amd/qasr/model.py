@@ -80,11 +80,25 @@ class Qwen3ASRModel:
         m._check(m.lib.qasr_finalize(m.h))
         return m
 
+    @classmethod
+    def borrowed(cls, handle, cfg):
+        """A view of an engine somebody else owns (qasr_dp_engine): every method works, close() leaves the engine alone."""
+        m = cls.__new__(cls)
+        m.lib = _lib.load(strict=True)
+        m.cfg = cfg
+        m.h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        m._keep = []
+        m._borrowed = True
+        return m
+
     def _check(self, rc):
         if rc != 0:
             raise QasrError(f"qasr error {rc}: {self.lib.qasr_last_error(self.h).decode()}")
 
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self.h = None
+            return
         if self.h:
             self.lib.qasr_destroy(self.h)
             self.h = None

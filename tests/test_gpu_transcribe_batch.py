@@ -66,6 +66,33 @@ def test_batched_run_equals_the_sequential_loop(model, tmp_path):
     assert [r["text"] for r in recs] == [seq["texts"][f"clip{k:02d}"] for k in range(3)]
 
 
+def test_groups_in_flight_give_the_same_texts(model, tmp_path):
+    """--lanes: groups go whole to engines sharing the GPU (qasr_dp_submit), two in flight; same texts, charges add up to the wall time."""
+    from qasr.dp import Qwen3ASRDataParallel
+    d = tmp_path / "audio"
+    d.mkdir()
+    for k in range(9):
+        _write_wav(d / f"clip{k:02d}.wav", synth.synth_waveform(k, 0.6 + 0.35 * (k % 4)))
+    _write_wav(d / "clip04b_24k.wav", synth.synth_waveform(9, 0.5), rate=24000)
+    files = TB.find_audio_files(str(d))
+    seq = TB.run(model, files, batch=1, out=io.StringIO(), max_tokens=20)
+    sd = synth.synth_state_dict(QC.AUDIO_TINY, QC.TEXT_TINY, seed=11, init="stress")
+    dp = Qwen3ASRDataParallel.from_state_dict(sd, [0, 0], preset="tiny", max_batch=4, max_audio_seconds=4, max_new_tokens=24)
+    try:
+        view = dp.engine(0)
+        view.set_vocab({i: ("Ġw%d" % i if i % 3 else "x%d" % i) for i in range(view.cfg.vocab)})
+        out = io.StringIO()
+        r = TB.run(view, files, batch=2, out=out, max_tokens=20, lanes=dp)
+        assert r["texts"] == seq["texts"] and len(r["texts"]) == 9
+        order = [int(m.group(1)) for m in re.finditer(r"^  \[(\d+)/10\]", out.getvalue(), re.M)]
+        assert order == list(range(1, 11))                                       # reported in file order, the error line in its place
+        assert r["total_inference"] <= r["wall"] + 1e-6 and r["total_inference"] > 0.5 * r["wall"]
+        view.close()                                                             # a view: the engine stays with dp
+        assert dp.transcribe_batch([synth.synth_waveform(0, 0.6)], max_tokens=5)
+    finally:
+        dp.close()
+
+
 def test_empty_directory(model, tmp_path):
     out = io.StringIO()
     r = TB.run(model, [], out=out)
