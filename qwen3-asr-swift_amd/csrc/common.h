@@ -78,6 +78,29 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B frag
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
 
+// 16-byte LDS read through a NATIVE vector type.  hipcc puts s_waitcnt vmcnt(0) in front of an LDS read whose pointee is a
+// HIP_vector_type (float4 / uint4 / uint2: no type-based alias info) whenever global_load_lds copies or global stores are outstanding --
+// under a direct-to-LDS prefetch that ends the prefetch at the read instead of at the barrier meant for it.
+__device__ __forceinline__ float4 lds_read_f4(const float* p) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// "These registers are read here": an empty asm that uses every 32-bit word of a loaded value.  hipcc places the s_waitcnt for a load at
+// its first use; when that use sits in a conditional block (a guarded store), the wait state is merged conservatively at every join and
+// each later guarded block gets its own s_waitcnt vmcnt(0) -- which then also waits for the stores issued in between.  A use in
+// unconditional code ahead of the guarded blocks leaves ONE wait.
+template <class T>
+__device__ __forceinline__ void reg_use(const T& t) {
+    static_assert(sizeof(T) % 4 == 0, "reg_use: whole 32-bit words");
+    if constexpr (sizeof(T) >= 4) {
+        unsigned w[sizeof(T) / 4];
+        __builtin_memcpy(w, &t, sizeof(T));
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 4; ++i) asm volatile("" ::"v"(w[i]));
+    }
+}
+
 // Cross-lane sums on the DPP path (v_add_f32 with a lane-permuting source operand, a few cycles) instead of __shfl_xor,
 // which hipcc lowers to ds_bpermute_b32: an LDS round trip (~100 cycles) per step, each behind its own s_waitcnt.
 //   quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E: sums of 4;  row_half_mirror 0x141: lane i <- 7 - i, completes 8;

@@ -470,7 +470,14 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
 // amdgpu_waves_per_eu(2, 2): without it hipcc spreads the accumulators over 202 VGPRs + 78 AGPRs = 280 registers, which
 // leaves ONE wave per SIMD (hipOccupancyMaxActiveBlocksPerMultiprocessor = 1; SQ_WAVE_CYCLES showed 0.8 waves per SIMD);
 // capped at 256 it needs 204 VGPRs, no spills, two workgroups per CU.
-template <int HD>
+//
+// VFRAG (round 3): V comes from the decode sweep's fragment-major image (cache.vf, vfrag_index: per 32 keys and 16 head dims one 1 KiB
+// block holding, lane by lane, exactly the 16-byte A fragment of O^T = V^T P^T -- keys {4g .. 4g+3, 16+4g .. 16+4g+3} of row d).  A 64-key
+// tile is 16 KiB contiguous in HBM (linear direct-to-LDS copy), a fragment is ONE lane-linear ds_read_b128 at a constant offset: no
+// address arithmetic, no bank conflicts, none of the register moves the two-8-byte-reads form needed (hipcc paired the reads of
+// neighbouring d tiles into ds_read2st64 and moved the halves together: 48 v_mov per tile).  The transposed V^T image stays for
+// engines without the fragment image (forced aligner).  Staging and read addresses are per-lane constants + a wave-uniform base.
+template <int HD, bool VFRAG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_attention2_kernel(const bf16_t* __restrict__ qr, KVLayout cache,
                                                                  const bf16_t* __restrict__ vt, int vt_stride,
                                                                  const int* __restrict__ cu,
@@ -497,23 +504,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16_t* vbase = vt + ((long)sl * cache.kv_heads + kvh) * HD * vt_stride;
     const int qw = q0 + wave * 16, qpos = qw + fr;
 
-    auto stage = [&](int buf, int k0) {
+    // per-lane constants of the tile copies (bytes from the tile's wave-uniform base)
+    unsigned koff[K_IPW], voff[V_IPW];
 #pragma unroll
-        for (int i = 0; i < K_IPW; ++i) {
-            const int inst = wave * K_IPW + i;
-            const int r = inst * K_RPI + lane / KCH, c = lane % KCH;
-            int key = k0 + r;
-            key = key < cache.max_ctx ? key : cache.max_ctx - 1;          // rows past the prompt are masked, not read as data
-            const bf16_t* src = kbase + (long)key * HD + ((c ^ (r & (KCH - 1))) << 3);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&smem[buf][0][inst * 1024], 16, 0, 0);
-        }
+    for (int i = 0; i < K_IPW; ++i) {
+        const int r = (wave * K_IPW + i) * K_RPI + lane / KCH, c = lane % KCH;
+        koff[i] = (unsigned)(r * HD + ((c ^ (r & (KCH - 1))) << 3)) * 2u;
+    }
 #pragma unroll
-        for (int i = 0; i < V_IPW; ++i) {
-            const int inst = wave * V_IPW + i;
+    for (int i = 0; i < V_IPW; ++i) {
+        const int inst = wave * V_IPW + i;
+        if (VFRAG) voff[i] = (unsigned)(inst * 1024 + lane * 16);
+        else {
             const int d = inst * 8 + (lane >> 3), c = lane & 7;
-            const bf16_t* src = vbase + (long)d * vt_stride + k0 + ((c ^ (d & 7)) << 3);   // V^T is zero past the prompt
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&smem[buf][1][inst * 1024], 16, 0, 0);
+            voff[i] = (unsigned)(d * vt_stride + ((c ^ (d & 7)) << 3)) * 2u;           // V^T is zero past the prompt
         }
+    }
+    const char* vsrc = VFRAG ? reinterpret_cast<const char*>(cache.vf + cache.off(sl, kvh, 0)) : reinterpret_cast<const char*>(vbase);
+    auto stage = [&](int buf, int k0) {
+        const char* kb = reinterpret_cast<const char*>(kbase) + (long)k0 * (HD * 2);
+        if (k0 + KT <= cache.max_ctx) {
+#pragma unroll
+            for (int i = 0; i < K_IPW; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(kb + koff[i]), (lds_ptr_t)&smem[buf][0][(wave * K_IPW + i) * 1024], 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < K_IPW; ++i) {
+                const int inst = wave * K_IPW + i;
+                const int r = inst * K_RPI + lane / KCH, c = lane % KCH;
+                int key = k0 + r;
+                key = key < cache.max_ctx ? key : cache.max_ctx - 1;      // rows past the prompt are masked, not read as data
+                const bf16_t* src = kbase + (long)key * HD + ((c ^ (r & (KCH - 1))) << 3);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&smem[buf][0][inst * 1024], 16, 0, 0);
+            }
+        }
+        // fragment image: 32 keys = DT KiB; transposed image: 2 bytes per key along a row
+        const char* vb = vsrc + (VFRAG ? (long)(k0 / 32) * (DT * 1024) : (long)k0 * 2);
+#pragma unroll
+        for (int i = 0; i < V_IPW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(vb + voff[i]), (lds_ptr_t)&smem[buf][1][(wave * V_IPW + i) * 1024], 16, 0, 0);
     };
 
     const int q_hi = min(q0 + 64, T);                     // causal: keys < q_hi
@@ -539,6 +568,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float m_run[REP], l_run[REP];
 #pragma unroll
     for (int mi = 0; mi < REP; ++mi) { m_run[mi] = -INFINITY; l_run[mi] = 0.0f; }
+    // LDS read offsets inside a tile: K fragment (key = nb * 16 + fr, k-step s) = kaddr[s] + nb * 16 rows; V fragment at a lane-linear
+    // offset (VFRAG) or the two 8-byte halves of the swizzled V^T row
+    unsigned kaddr[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kaddr[s] = (unsigned)(fr * (HD * 2) + (((s * 4 + g) ^ (fr & (KCH - 1))) << 4));
+    const bf16x2_native ones2 = __builtin_bit_cast(bf16x2_native, 0x3f803f80u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA completion is tracked by vmcnt only (also covers qf)
     __syncthreads();
 
@@ -551,11 +586,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f32x4 sc[REP][4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const int key = nb * 16 + fr;
                 mfma_bf16x8 kf[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
-                    kf[s] = *reinterpret_cast<const mfma_bf16x8*>(s_k + key * (HD * 2) + (((s * 4 + g) ^ (key & (KCH - 1))) << 4));
+                    kf[s] = *reinterpret_cast<const mfma_bf16x8*>(s_k + nb * (16 * HD * 2) + kaddr[s]);
 #pragma unroll
                 for (int mi = 0; mi < REP; ++mi) {
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -584,8 +618,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mx = fmaxf(mx, sc[mi][nb][j]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                {   // the row's other keys live on the lanes fr + 16 g': v_permlane16_swap / v_permlane32_swap instead of two LDS round trips
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                    mx = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                    mx = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+                }
                 const float m_new = fmaxf(m_run[mi], mx);                  // raw score units (scale > 0 keeps the order)
                 const float m_ref = m_new == -INFINITY ? 0.0f : m_new;     // rows past the prompt keep m = -inf
                 const float alpha = __builtin_amdgcn_exp2f((m_run[mi] - m_ref) * c2);
@@ -597,7 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int j = 0; j < 4; j += 2) {
                         const unsigned pw = pack_bf16x2(__builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j], c2, mc)),
                                                         __builtin_amdgcn_exp2f(fmaf(sc[mi][nb][j + 1], c2, mc)));
-                        rs += bf16_lo(pw) + bf16_hi(pw);
+                        rs = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_native, pw), ones2, rs, false);   // sum of the ROUNDED P
                         // k-slot order of the P V^T product: slots 0-3 <- keys 4g+j of the even 16-key block, 4-7 <- the odd one
                         pk[mi][nb >> 1][(nb & 1) * 2 + j / 2] = pw;
                     }
@@ -616,12 +654,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     pb[mi] = __builtin_bit_cast(mfma_bf16x8, make_uint4(pk[mi][p][0], pk[mi][p][1], pk[mi][p][2], pk[mi][p][3]));
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
-                    const int dr = d * 16 + fr;
-                    // A operand rows = d; k-slots 8g..8g+7 <- keys {32p + 4g + j, 32p + 16 + 4g + j}: two 8-byte reads
-                    const char* vrow = s_v + dr * 128 + (g & 1) * 8;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((4 * p + (g >> 1)) ^ (dr & 7)) << 4));
-                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((4 * p + 2 + (g >> 1)) ^ (dr & 7)) << 4));
-                    const mfma_bf16x8 vf = __builtin_bit_cast(mfma_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    mfma_bf16x8 vf;
+                    if constexpr (VFRAG) {
+                        vf = *reinterpret_cast<const mfma_bf16x8*>(s_v + (p * DT + d) * 1024 + lane * 16);
+                    } else {
+                        const int dr = d * 16 + fr;
+                        // A operand rows = d; k-slots 8g..8g+7 <- keys {32p + 4g + j, 32p + 16 + 4g + j}: two 8-byte reads.  Native vector
+                        // types: a read through HIP_vector_type (uint2) carries no alias info and hipcc puts s_waitcnt vmcnt(0) in front of
+                        // it while the next tile's global_load_lds are in flight -- the prefetch would end here, not at the barrier
+                        typedef unsigned __attribute__((ext_vector_type(2))) u32x2_n;
+                        typedef unsigned __attribute__((ext_vector_type(4))) u32x4_n;
+                        const char* vrow = s_v + dr * 128 + (g & 1) * 8;
+                        const u32x2_n lo = *reinterpret_cast<const u32x2_n*>(vrow + (((4 * p + (g >> 1)) ^ (dr & 7)) << 4));
+                        const u32x2_n hi = *reinterpret_cast<const u32x2_n*>(vrow + (((4 * p + 2 + (g >> 1)) ^ (dr & 7)) << 4));
+                        vf = __builtin_bit_cast(mfma_bf16x8, u32x4_n{lo.x, lo.y, hi.x, hi.y});
+                    }
 #pragma unroll
                     for (int mi = 0; mi < REP; ++mi) o[mi][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[mi], o[mi][d], 0, 0, 0);
                 }
@@ -658,10 +705,14 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
     if (form >= 2 && heads == 2 * cache.kv_heads && (cache.hd == 128 || cache.hd == 32)) {
         const int hf = tuning().pa_order != 0 && cache.kv_heads == 8 ? 1 : 0;     // A/B knob; the XCD argument holds for 8 kv heads
         const dim3 grid = hf ? dim3(cache.kv_heads, n_clips, cdiv(max_len, 64)) : dim3(cdiv(max_len, 64), cache.kv_heads, n_clips);
-        if (cache.hd == 128)
-            hipLaunchKernelGGL((prefill_attention2_kernel<128>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
-        else
-            hipLaunchKernelGGL((prefill_attention2_kernel<32>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
+        const bool vfrag = cache.vf != nullptr && tuning().pa_vfrag != 0;      // A/B knob; engines without the fragment image: V^T
+        if (cache.hd == 128) {
+            if (vfrag) hipLaunchKernelGGL((prefill_attention2_kernel<128, true>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
+            else hipLaunchKernelGGL((prefill_attention2_kernel<128, false>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
+        } else {
+            if (vfrag) hipLaunchKernelGGL((prefill_attention2_kernel<32, true>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
+            else hipLaunchKernelGGL((prefill_attention2_kernel<32, false>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
+        }
         return;
     }
     if (cache.hd == 128 && mt == 2)

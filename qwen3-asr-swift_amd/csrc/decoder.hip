@@ -443,7 +443,7 @@ void Engine::run_prefill(bool want_logits) {
                     aligner ? nullptr : vfcache_[l]->as<bf16_t>()};
         const PromptW W = prompt_weights(l, s);
         rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
-        gemm_nt(ADense{h, H, P, H}, W.wqkv, H, P, nh * hd, H, EpiBiasActBf16<0>{qkv, (long)nh * hd, nullptr}, s);
+        gemm_nt(ADense{h, H, P, H}, W.wqkv, H, P, nh * hd, H, EpiStoreBf16{qkv, (long)nh * hd}, s);
         qk_norm_rope_launch(qkv, d_p_slot_, d_p_pos_, P, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
                             d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), qr, kv, d_vt_.as<bf16_t>(), vt_stride_,
                             d_p_cu_, d_p_slotclip_, batch_, max_len_, s);
@@ -451,7 +451,7 @@ void Engine::run_prefill(bool want_logits) {
                                  cfg_.heads, at, s);
         gemm_nt(ADense{at, nq, P, nq}, W.wo, nq, P, H, nq, EpiResidBf16{x, H}, s);
         rmsnorm_rows_launch(x, L.ln2, h, P, H, cfg_.rms_eps, s);
-        gemm_nt_swiglu(ADense{h, H, P, H}, W.wgu, H, P, 2 * I, H, EpiBiasActBf16<0>{act, I, nullptr}, s);
+        gemm_nt_swiglu(ADense{h, H, P, H}, W.wgu, H, P, 2 * I, H, EpiStoreBf16{act, I}, s);
         gemm_nt(ADense{act, I, P, I}, W.wdown, I, P, H, I, EpiResidBf16{x, H}, s);
     }
     if (cfg_.classify_num > 0) { QASR_HIP(hipGetLastError()); return; }      // aligner: the caller reads d_px_ rows
@@ -944,10 +944,10 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                                     L.kn, cfg_.rms_eps, rr.cos_rows, rr.sin_rows, kv, d_dattn_.as<bf16_t>(), s);
         } else if (which == 3) {      // prompt-pass QKV GEMM shape (M = packed prompt rows, N = 4096, K = 1024)
             gemm_nt(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, probe_w.wqkv, H, n_pos_, nh * hd, H,
-                    EpiBiasActBf16<0>{d_pqkv_.as<bf16_t>(), (long)nh * hd, nullptr}, s);
+                    EpiStoreBf16{d_pqkv_.as<bf16_t>(), (long)nh * hd}, s);
         } else if (which == 4) {      // prompt-pass gate/up GEMM with the SwiGLU epilogue
             gemm_nt_swiglu(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, probe_w.wgu, H, n_pos_, 2 * I, H,
-                           EpiBiasActBf16<0>{d_pact_.as<bf16_t>(), I, nullptr}, s);
+                           EpiStoreBf16{d_pact_.as<bf16_t>(), I}, s);
         } else {
             run_lm_head(false, 0, batch_, s);
         }

@@ -124,6 +124,16 @@ __device__ __forceinline__ int gemm_lds_off(int row, int chunk) { return row * 1
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// epilogue traits: an epilogue with a nested `Pre` splits into prefetch(m, n) -> Pre (its memory reads) and apply(m, n, v, pre)
+template <class E, class = void>
+struct epi_has_pre { static constexpr bool value = false; };
+template <class E>
+struct epi_has_pre<E, std::void_t<typename E::Pre>> { static constexpr bool value = true; };
+template <class E, bool HAS>
+struct epi_pre_type { struct type {}; };
+template <class E>
+struct epi_pre_type<E, true> { using type = typename E::Pre; };
+
 template <class ALoad, class Epi, int MODE, int NBUF>
 __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBUF][A|B][128 rows x 128 B] */, const ALoad& aload,
                                                  const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, const Epi& epi,
@@ -214,6 +224,9 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
     // HALVES passes of 64 x (64 / HALVES) floats (one pass with 64 KiB of LDS, two 32-column halves with 32 KiB)
     constexpr int HALVES = NBUF == 2 ? 1 : 2, CW = 64 / HALVES;
     float* ct = reinterpret_cast<float*>(smem) + wave * (64 * CW);
+    // (Measured and dropped in round 3: all of a half's epilogue requests -- residual rows, bias -- issued before its LDS image is written
+    // and applied from registers.  The per-row form below costs a request -> wait -> store round trip per row in the ISA, but the 4-5
+    // co-resident workgroups of this form cover it; the batched form's 16-64 extra registers cost more: encoder +0.55 ms per pass.)
 #pragma unroll
     for (int h = 0; h < HALVES; ++h) {
         if (h) __syncthreads();
@@ -231,7 +244,7 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
             for (int it = 0; it < 64 / RPI; ++it) {
                 const int row = it * RPI + er;
                 const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * CW + ec;
-                if (m < M && n < N) epi(m, n, *reinterpret_cast<const float4*>(&ct[row * CW + ec]));
+                if (m < M && n < N) epi(m, n, lds_read_f4(&ct[row * CW + ec]));
             }
         } else {
             // 32-column blocks = 16 gate + 16 up: a lane takes 4 fused outputs of one block
@@ -242,8 +255,8 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
                 const int row = it * RPS + er;
                 const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + h * CW + blk * 32;
                 if (m < M && n < N) {
-                    const float4 g = *reinterpret_cast<const float4*>(&ct[row * CW + blk * 32 + e]);
-                    const float4 u = *reinterpret_cast<const float4*>(&ct[row * CW + blk * 32 + 16 + e]);
+                    const float4 g = lds_read_f4(&ct[row * CW + blk * 32 + e]);
+                    const float4 u = lds_read_f4(&ct[row * CW + blk * 32 + 16 + e]);
                     float4 v;
                     v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
                     v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);
@@ -367,10 +380,6 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
 // workgroups (gemm_p8.h): a nested type Pre, `Pre prefetch(m, n)` = the loads only, `apply(m, n, acc, pre)` = the rest;
 // operator() == apply(prefetch).  The caller issues the prefetch of the next output rows before it applies the current ones.
 // ------------------------------------------------------------------------------------------------
-template <class E, class = void>
-struct epi_has_pre { static constexpr bool value = false; };
-template <class E>
-struct epi_has_pre<E, std::void_t<typename E::Pre>> { static constexpr bool value = true; };
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     uint2 o;
@@ -403,6 +412,16 @@ struct EpiBiasActBf16 {
         *reinterpret_cast<uint2*>(out + (long)m * ldo + n) = pack_bf16x4(v);
     }
     __device__ __forceinline__ void operator()(int m, int n, float4 v) const { apply(m, n, v, prefetch(m, n)); }
+};
+
+// out_bf16[m][n] = bf16(acc): the Qwen3 text decoder's Linears carry no bias.  With no load in the epilogue there is nothing for it to
+// wait on: behind EpiBiasActBf16's `bias ? load : 0` hipcc keeps an s_waitcnt vmcnt(0) per round, which in the 256^2 form also waits for
+// the next tile's first K-tile (in flight under the epilogue by design) and for the round's own stores.
+struct EpiStoreBf16 {
+    bf16_t* out; long ldo;
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
+        *reinterpret_cast<uint2*>(out + (long)m * ldo + n) = pack_bf16x4(v);
+    }
 };
 
 // x_f32[m][n] += acc + bias[n]   (encoder residual stream, f32)

@@ -31,10 +31,6 @@ namespace qasr {
 
 constexpr int P8_BM = 256, P8_BN = 256, P8_THREADS = 512, P8_UNIT = 16384, P8_TM = 4;
 
-template <class E, bool HAS>
-struct epi_pre_type { struct type {}; };
-template <class E>
-struct epi_pre_type<E, true> { using type = typename E::Pre; };
 
 template <class ALoad, class Epi, int MODE>
 __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N,
@@ -201,10 +197,6 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     // next tile: its first K-tile goes to the parity-0 half of the ring now, in flight under this tile's epilogue
     lt += wgs_per_xcd;
     const bool more = lt < t_end;
-    if (more) {
-        tile_rows(lt);
-        stage_first();
-    }
     // epilogue: eight rounds (64-row half, 32-column half, 32-row half) through this wave's 32 x 36-float image in the
     // parity-1 half of the ring
     constexpr int LDC = 36;
@@ -230,6 +222,10 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
     struct NoPre {};
     using PreT = typename std::conditional<PRE, typename epi_pre_type<Epi, PRE>::type, NoPre>::type;
     PreT pre[4] = {}, nxt[4] = {};
+    if (more) {
+        tile_rows(lt);
+        stage_first();
+    }
     prefetch_round(0, pre);
 #pragma unroll
     for (int rd = 0; rd < 8; ++rd) {
@@ -250,7 +246,7 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
         if (MODE == 0) {
             float4 v[4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const float4*>(&ct[(it * 8 + er0) * LDC + ec0]);
+            for (int it = 0; it < 4; ++it) v[it] = lds_read_f4(&ct[(it * 8 + er0) * LDC + ec0]);
             if (rd < 7) prefetch_round(rd + 1, nxt);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -268,8 +264,8 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
             for (int it = 0; it < 2; ++it) {
                 const int row = it * 16 + er;
                 if (mb + row < M && nb < N) {
-                    const float4 g = *reinterpret_cast<const float4*>(&ct[row * LDC + e]);
-                    const float4 u = *reinterpret_cast<const float4*>(&ct[row * LDC + 16 + e]);
+                    const float4 g = lds_read_f4(&ct[row * LDC + e]);
+                    const float4 u = lds_read_f4(&ct[row * LDC + 16 + e]);
                     float4 v;
                     v.x = gemm_swiglu(g.x, u.x); v.y = gemm_swiglu(g.y, u.y);
                     v.z = gemm_swiglu(g.z, u.z); v.w = gemm_swiglu(g.w, u.w);

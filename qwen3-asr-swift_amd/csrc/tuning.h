@@ -21,6 +21,7 @@ struct Tuning {
     int da_earlyq = 0;       // 1: the token's own q / k / v rows requested ahead of the K / V stream (loads return in order; +-0, measured) | 0 after it
     int pa_form = 2;         // prompt attention: 2 transposed-score form | 1 first form (a third, 32x32x16 form was measured and dropped:
                              // profiles/r02_ab_prompt_attention_form3.txt)
+    int pa_vfrag = 1;        // prompt attention V operand: 1 the decode sweep's fragment-major image (one lane-linear 16-byte read per fragment) | 0 V^T rows
     int pa_order = 1;        // prompt attention workgroup order: 1 longest query tiles first, kv head = XCD | 0 query tile fastest
     int pa_mt = 1;           // row tiles per wave of the first form
     int qknr_wide = 1;       // q/k norm + RoPE of the prompt pass: 16-byte accesses
