@@ -32,8 +32,7 @@ void gather_rows_launch(const bf16_t* src, const int* row_idx, bf16_t* dst, int 
 // ---- prefill -------------------------------------------------------------------------------------
 struct KVLayout {          // one layer's cache, bf16, per (slot, kv head) a block of max_ctx * hd elements
     bf16_t* k;             // keys [slot][kv_head][max_ctx][hd]
-    bf16_t* v;             // values in the same row-major form: PROMPT-PASS SCRATCH shared by all layers (qk_norm_rope
-                           // writes it, v_transpose reads it back in the same layer); decode never touches it
+    bf16_t* v;             // unused since round 3 (was a row-major V scratch of the prompt pass; v_transpose now reads V from qkv): null
     int max_ctx, kv_heads, hd;
     // the values the decode sweep reads: MFMA-fragment order [key/32][d/16][lane 64][8], see vfrag_index() in
     // dec_attention.hip; written by v_transpose (prompt) and decode_attention (append)
@@ -44,7 +43,7 @@ struct KVLayout {          // one layer's cache, bf16, per (slot, kv head) a blo
 };
 
 // Per packed prompt position p: q/k RMSNorm over head_dim, RoPE at position pos[p], then
-//   q  -> qr[p][head][hd]; k -> cache.k[slot][kvh][pos]; v -> cache.v[...] and vt[slot][kvh][d][pos]
+//   q  -> qr[p][head][hd]; k -> cache.k[slot][kvh][pos]; v (no arithmetic) -> cache.vf fragments and, where the prompt attention reads V^T, vt[slot][kvh][d][pos]
 // qkv: [n_pos][(heads + 2 kv) * hd]  (q | k | v).   rope tables: [max_pos][hd/2] f32.
 void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads,
                          int hd, const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,

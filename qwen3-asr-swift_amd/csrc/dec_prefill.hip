@@ -102,12 +102,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     const int sl = slot[p], ps = pos[p];
     const unsigned a = *reinterpret_cast<const unsigned*>(src + 2 * j);
     const unsigned bb = *reinterpret_cast<const unsigned*>(src + HALF + 2 * j);
-    if (h >= heads + kv_heads) {                        // V: plain copy (the transposed image is built separately)
-        bf16_t* dv = cache.v + cache.off(sl, h - heads - kv_heads, ps);
-        *reinterpret_cast<unsigned*>(dv + 2 * j) = a;
-        *reinterpret_cast<unsigned*>(dv + HALF + 2 * j) = bb;
-        return;
-    }
+    if (h >= heads + kv_heads) return;                  // V needs no arithmetic: v_transpose_kernel reads it from qkv
     const float x1a = bf16_to_f32((bf16_t)(a & 0xffff)), x1b = bf16_to_f32((bf16_t)(a >> 16));
     const float x2a = bf16_to_f32((bf16_t)(bb & 0xffff)), x2b = bf16_to_f32((bf16_t)(bb >> 16));
     float ss = (x1a * x1a + x1b * x1b) + (x2a * x2a + x2b * x2b);
@@ -139,7 +134,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_wide_kernel(const bf16_t* __
                                                                 KVLayout cache) {
     constexpr int LPH = HD / 16, HPW = 64 / LPH, HALF = HD / 2;
     const int nh = heads + 2 * kv_heads;
-    const int groups = nh / HPW;                        // head groups per position (host checks nh % HPW == 0)
+    // head groups per position: the q and k heads only (host checks (heads + kv_heads) % HPW == 0) -- V needs no arithmetic, the
+    // transposing kernel below reads it from qkv directly
+    const int groups = (heads + kv_heads) / HPW;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wid >= (long)n_pos * groups) return;
@@ -149,12 +146,6 @@ __global__ __launch_bounds__(256) void qk_norm_rope_wide_kernel(const bf16_t* __
     const int sl = slot[p], ps = pos[p];
     const uint4 a = *reinterpret_cast<const uint4*>(src + 8 * j);
     const uint4 b = *reinterpret_cast<const uint4*>(src + HALF + 8 * j);
-    if (h >= heads + kv_heads) {                        // V: plain copy (the transposed image is built separately)
-        bf16_t* dv = cache.v + cache.off(sl, h - heads - kv_heads, ps);
-        *reinterpret_cast<uint4*>(dv + 8 * j) = a;
-        *reinterpret_cast<uint4*>(dv + HALF + 8 * j) = b;
-        return;
-    }
     const bf16_t* ae = reinterpret_cast<const bf16_t*>(&a);
     const bf16_t* be = reinterpret_cast<const bf16_t*>(&b);
     float x1[8], x2[8], ss = 0.0f;
@@ -191,30 +182,31 @@ __global__ __launch_bounds__(256) void qk_norm_rope_wide_kernel(const bf16_t* __
     *reinterpret_cast<uint4*>(dst + HALF + 8 * j) = o2;
 }
 
-// V^T image for the prompt pass: cache.v rows [pos][HD] -> vt[slot][kvh][d][pos], 64 positions per workgroup,
-// transposed through LDS so both sides move 128-byte rows.
+// V images for the prompt pass and the decode sweep, 64 positions per workgroup, transposed through LDS so both sides move 128-byte
+// rows: the V third of qkv (packed prompt rows cu[clip] + pos, head heads + kv_heads + kvh) -> vt[slot][kvh][d][pos] (only when the
+// prompt attention reads V^T: engines without the fragment image, or the pa_vfrag = 0 A/B) and -> cache.vf (fragment-major).
 template <int HD>
-__global__ __launch_bounds__(256) void v_transpose_kernel(KVLayout cache, const int* __restrict__ cu,
-                                                          const int* __restrict__ slot_of_clip,
+__global__ __launch_bounds__(256) void v_transpose_kernel(KVLayout cache, const bf16_t* __restrict__ qkv, int nh, int vhead0,
+                                                          const int* __restrict__ cu, const int* __restrict__ slot_of_clip,
                                                           bf16_t* __restrict__ vt, int vt_stride) {
     __shared__ bf16_t tile[64][HD + 2];
     const int clip = blockIdx.z, kvh = blockIdx.y, p0 = blockIdx.x * 64;
     const int T = cu[clip + 1] - cu[clip];
     if (p0 >= T) return;
     const int sl = slot_of_clip[clip], tid = threadIdx.x;
-    const bf16_t* src = cache.v + cache.off(sl, kvh, p0);
+    const bf16_t* src = qkv + ((long)(cu[clip] + p0) * nh + vhead0 + kvh) * HD;
     constexpr int CH = HD / 8;
     for (int i = tid; i < 64 * CH; i += 256) {
         const int r = i / CH, ch = i - r * CH;
         uint4 u = make_uint4(0, 0, 0, 0);
-        if (p0 + r < T) u = *reinterpret_cast<const uint4*>(src + (long)r * HD + ch * 8);
+        if (p0 + r < T) u = *reinterpret_cast<const uint4*>(src + (long)r * nh * HD + ch * 8);
         const bf16_t* e = reinterpret_cast<const bf16_t*>(&u);
 #pragma unroll
         for (int q = 0; q < 8; ++q) tile[r][ch * 8 + q] = e[q];
     }
     __syncthreads();
-    bf16_t* dst = vt + ((long)sl * cache.kv_heads + kvh) * HD * vt_stride + p0;
-    for (int i = tid; i < HD * 8; i += 256) {            // 8 chunks of 8 positions per d row
+    bf16_t* dst = vt ? vt + ((long)sl * cache.kv_heads + kvh) * HD * vt_stride + p0 : nullptr;
+    for (int i = tid; dst && i < HD * 8; i += 256) {     // 8 chunks of 8 positions per d row
         const int d = i >> 3, ch = i & 7;
         uint4 o;
         bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
@@ -243,24 +235,25 @@ void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int
     if (n_pos <= 0) return;
     const int nh = heads + 2 * kv_heads;
     const int wide = tuning().qknr_wide;      // A/B knob
-    if (hd == 128 && nh % 8 == 0 && wide) {
-        long waves = (long)n_pos * (nh / 8);
+    // the prompt attention reads V^T only without the fragment image (forced aligner) or under the pa_vfrag = 0 A/B
+    bf16_t* vt_out = (cache.vf == nullptr || tuning().pa_vfrag == 0) ? vt : nullptr;
+    if (!vt_out && !cache.vf) throw std::invalid_argument("qk_norm_rope: no V image to write");
+    const dim3 tgrid(cdiv(max_len, 64), kv_heads, n_clips);
+    if (hd == 128 && (heads + kv_heads) % 8 == 0 && wide) {
+        long waves = (long)n_pos * ((heads + kv_heads) / 8);
         hipLaunchKernelGGL(qk_norm_rope_wide_kernel<128>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
                            kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache);
-        if (vt) hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(cdiv(max_len, 64), kv_heads, n_clips), dim3(256), 0, s,
-                                   cache, cu, slot_of_clip, vt, vt_stride);
+        hipLaunchKernelGGL(v_transpose_kernel<128>, tgrid, dim3(256), 0, s, cache, qkv, nh, heads + kv_heads, cu, slot_of_clip, vt_out, vt_stride);
     } else if (hd == 128 && nh % 2 == 0) {
         long waves = (long)n_pos * (nh / 2);
         hipLaunchKernelGGL(qk_norm_rope_kernel<128>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
                            kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache);
-        if (vt) hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(cdiv(max_len, 64), kv_heads, n_clips), dim3(256), 0, s,
-                                   cache, cu, slot_of_clip, vt, vt_stride);
+        hipLaunchKernelGGL(v_transpose_kernel<128>, tgrid, dim3(256), 0, s, cache, qkv, nh, heads + kv_heads, cu, slot_of_clip, vt_out, vt_stride);
     } else if (hd == 32 && nh % 8 == 0) {
         long waves = (long)n_pos * (nh / 8);
         hipLaunchKernelGGL(qk_norm_rope_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, s, qkv, slot, pos, n_pos, heads,
                            kv_heads, qn_w, kn_w, eps, rope_cos, rope_sin, qr, cache);
-        if (vt) hipLaunchKernelGGL(v_transpose_kernel<32>, dim3(cdiv(max_len, 64), kv_heads, n_clips), dim3(256), 0, s,
-                                   cache, cu, slot_of_clip, vt, vt_stride);
+        hipLaunchKernelGGL(v_transpose_kernel<32>, tgrid, dim3(256), 0, s, cache, qkv, nh, heads + kv_heads, cu, slot_of_clip, vt_out, vt_stride);
     } else {
         throw std::invalid_argument("qk_norm_rope: unsupported (head_dim, head count)");
     }

@@ -247,7 +247,6 @@ void Engine::finalize_decoder() {
     kcache_.clear();
     vfcache_.clear();
     const size_t cache_bytes = (size_t)B * cfg_.kv_heads * max_ctx_ * hd * sizeof(bf16_t);
-    d_vrows_.alloc(cache_bytes);          // row-major V of the layer in flight (prompt pass only)
     for (int i = 0; i < (aligner ? 1 : cfg_.dec_layers); ++i) {
         kcache_.push_back(std::make_unique<DevBuf>());
         kcache_.back()->alloc(cache_bytes);
@@ -439,7 +438,7 @@ void Engine::run_prefill(bool want_logits) {
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
         const bool aligner = cfg_.classify_num > 0;
-        KVLayout kv{kcache_[aligner ? 0 : l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd,
+        KVLayout kv{kcache_[aligner ? 0 : l]->as<bf16_t>(), nullptr, max_ctx_, cfg_.kv_heads, hd,
                     aligner ? nullptr : vfcache_[l]->as<bf16_t>()};
         const PromptW W = prompt_weights(l, s);
         rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
@@ -566,7 +565,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     const GreedyState gs = greedy_rows(r0);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
-        KVLayout kv{kcache_[l]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
+        KVLayout kv{kcache_[l]->as<bf16_t>(), nullptr, max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
         kv.k += kv.off(r0, 0, 0);
         kv.vf += kv.off(r0, 0, 0);
         // diagnostic (make DIAG=1): in-situ phase stamps of ONE layer's five launches inside a real step
@@ -913,7 +912,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     require_asr("kernel_probe");
     const int H = cfg_.hidden, hd = cfg_.head_dim, nq = cfg_.heads * hd, nh = cfg_.heads + 2 * cfg_.kv_heads, I = cfg_.inter;
     const DecLayerW& L = decw_.layers[0];
-    KVLayout kv{kcache_[0]->as<bf16_t>(), d_vrows_.as<bf16_t>(), max_ctx_, cfg_.kv_heads, hd, vfcache_[0]->as<bf16_t>()};
+    KVLayout kv{kcache_[0]->as<bf16_t>(), nullptr, max_ctx_, cfg_.kv_heads, hd, vfcache_[0]->as<bf16_t>()};
     hipStream_t s = stream_;
     std::vector<int> ctx(batch_);
     QASR_HIP(hipMemcpy(ctx.data(), gstate_.ctx_len, batch_ * sizeof(int), hipMemcpyDeviceToHost));

@@ -252,7 +252,6 @@ private:
     unsigned long long* stamp_buf_ = nullptr;                   // diagnostic in-situ stamps (kernel_probe, make DIAG=1)
     int stamp_layer_ = -1;
     DevBuf d_al_rows_, d_al_x_, d_al_logits_, d_al_idx_;         // aligner head workspace (grown on demand)
-    DevBuf d_vrows_;                                            // row-major V of one layer (prompt-pass scratch)
     DevBuf d_vt_;
     DevBuf d_px_, d_ph_, d_pqkv_, d_pqr_, d_pattn_, d_pact_;   // prefill (packed prompt positions)
     DevBuf d_dx_, d_dh_, d_dqkv_, d_dattn_, d_dact_, d_logits_, d_part_val_, d_part_idx_;   // decode rows

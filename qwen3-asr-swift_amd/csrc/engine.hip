@@ -117,7 +117,6 @@ void Engine::unload() {
     fused_.clear();
     kcache_.clear();
     vfcache_.clear();
-    d_vrows_.release();
     d_wscratch_.release();
     if (copy_stream_) QASR_HIP(hipStreamSynchronize(copy_stream_));
     staged_valid_ = false;
