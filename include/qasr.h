@@ -200,7 +200,8 @@ int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps);
 /* Dominant-kernel probe used by bench.py's roofline object: average duration (ms) of kernel
  * `which` over the last run measured with HIP events on the engine stream, plus its launch count
  * and algorithmic bytes per launch.  which: 0 = decode-step weight-streaming GEMV group,
- * 1 = decode attention, 2 = LM head; 3 / 4 = prompt-pass QKV / gate-up GEMM (bytes_per_launch then holds FLOPs). */
+ * 1 = decode attention, 2 = LM head; 3 / 4 = prompt-pass QKV / gate-up GEMM, 5 = prompt attention of one layer (bytes_per_launch
+ * then holds FLOPs; causal count for 5). */
 int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch);
 /* Diagnostic: the MFMA GEMM the encoder / prompt pass / wav2vec2 path are built on, by itself.  out[M][N] (f32, host) =
  * A[M][K] . W[N][K]^T + bias[N] with bf16 operands (host arrays of bf16 bit patterns), f32 accumulation, f32 bias (may be

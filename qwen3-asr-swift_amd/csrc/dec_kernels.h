@@ -55,7 +55,7 @@ void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int
 // oracle/decoder.py: flash_prefill_attention).  out: [n_pos][heads*hd] bf16.
 void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt, int vt_stride, const int* cu,
                               const int* slot_of_clip, int n_clips, int max_len, int heads, bf16_t* out,
-                              hipStream_t s);
+                              hipStream_t s, unsigned long long* dbg = nullptr);
 
 // ---- decode step (M = batch rows) -----------------------------------------------------------------
 enum DecEpi { DEC_EPI_BF16 = 0, DEC_EPI_RESID = 1, DEC_EPI_SWIGLU = 2, DEC_EPI_LOGITS = 3 };

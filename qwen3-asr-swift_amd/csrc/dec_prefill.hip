@@ -470,12 +470,18 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const bf16_t* __
 // address arithmetic, no bank conflicts, none of the register moves the two-8-byte-reads form needed (hipcc paired the reads of
 // neighbouring d tiles into ds_read2st64 and moved the halves together: 48 v_mov per tile).  The transposed V^T image stays for
 // engines without the fragment image (forced aligner).  Staging and read addresses are per-lane constants + a wave-uniform base.
-template <int HD, bool VFRAG>
+// STAMPS (qasr_kernel_probe 5 with the pa_stamps diagnostic knob, `make DIAG=1`): per wave, 100 MHz wall-clock sums of the loop's phases.
+template <int HD, bool VFRAG, bool STAMPS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_attention2_kernel(const bf16_t* __restrict__ qr, KVLayout cache,
                                                                  const bf16_t* __restrict__ vt, int vt_stride,
                                                                  const int* __restrict__ cu,
                                                                  const int* __restrict__ slot_of_clip, int heads,
-                                                                 bf16_t* __restrict__ out, float scale, int heavy_first) {
+                                                                 bf16_t* __restrict__ out, float scale, int heavy_first,
+                                                                 unsigned long long* __restrict__ dbg = nullptr) {
+    [[maybe_unused]] unsigned long long st_t0 = 0, st_prev = 0, st_sum[6] = {0, 0, 0, 0, 0, 0};
+    // phase p ends here: the time since the previous mark goes to st_sum[p]
+#define PA_MARK(p) do { if constexpr (STAMPS) { const unsigned long long t_ = wall_clock64(); st_sum[p] += t_ - st_prev; st_prev = t_; } } while (0)
+    if constexpr (STAMPS) { st_t0 = wall_clock64(); st_prev = st_t0; }
     constexpr int KT = 64, KS = HD / 32, DT = HD / 16, KCH = HD / 8, REP = 2;
     constexpr int TILE_BYTES = KT * HD * 2;                       // K tile and V^T tile have the same size
     constexpr int K_RPI = 64 / KCH, K_IPW = KT / K_RPI / 4;       // rows per wave instruction, instructions per wave
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     const char* vsrc = VFRAG ? reinterpret_cast<const char*>(cache.vf + cache.off(sl, kvh, 0)) : reinterpret_cast<const char*>(vbase);
-    auto stage = [&](int buf, int k0) {
+    auto stage_k = [&](int buf, int k0) {
         const char* kb = reinterpret_cast<const char*>(kbase) + (long)k0 * (HD * 2);
         if (k0 + KT <= cache.max_ctx) {
 #pragma unroll
@@ -531,12 +537,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&smem[buf][0][inst * 1024], 16, 0, 0);
             }
         }
+    };
+    auto stage_v = [&](int buf, int k0) {
         // fragment image: 32 keys = DT KiB; transposed image: 2 bytes per key along a row
         const char* vb = vsrc + (VFRAG ? (long)(k0 / 32) * (DT * 1024) : (long)k0 * 2);
 #pragma unroll
         for (int i = 0; i < V_IPW; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(vb + voff[i]), (lds_ptr_t)&smem[buf][1][(wave * V_IPW + i) * 1024], 16, 0, 0);
     };
+    auto stage = [&](int buf, int k0) { stage_k(buf, k0); stage_v(buf, k0); };
 
     const int q_hi = min(q0 + 64, T);                     // causal: keys < q_hi
     const int n_tiles = (q_hi + KT - 1) / KT;
@@ -569,10 +578,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16x2_native ones2 = __builtin_bit_cast(bf16x2_native, 0x3f803f80u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA completion is tracked by vmcnt only (also covers qf)
     __syncthreads();
+    PA_MARK(0);                                         // prologue: cu / slot reads, first tile's copy, query fragments
 
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int cur = kt & 1, k0 = kt * KT;
-        if (kt + 1 < n_tiles) stage(cur ^ 1, k0 + KT);    // streams in under this tile's MFMAs
+        // the next tile streams in under this tile's MFMAs.  (Requesting its V half after the S^T block instead -- so that the eight waves of
+        // a CU do not push 64 KB into the 64 B/clk L1 fill path in one burst -- measured +-0: profiles/r03_stamps_prompt_attention.txt)
+        if (kt + 1 < n_tiles) stage(cur ^ 1, k0 + KT);
+        PA_MARK(1);                                     // copy requests issued
         if (k0 <= qw + 15 && qw < T) {                    // this wave has unmasked keys in the tile (wave-uniform)
             const char* s_k = smem[cur][0];
             const char* s_v = smem[cur][1];
@@ -591,6 +604,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     sc[mi][nb] = acc;
                 }
             }
+            if constexpr (STAMPS) { asm volatile("s_nop 0" ::"v"(sc[REP - 1][3][3])); }    // the last score is in its register
+            PA_MARK(2);                                 // S^T
             unsigned pk[REP][2][4];
             // only the tile on the diagonal (or the prompt's last tile) needs the per-key mask (wave-uniform)
             const bool full = k0 + KT - 1 <= qw && k0 + KT <= T;
@@ -639,6 +654,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[mi][d][j] *= alpha;
             }
+            PA_MARK(3);                                 // softmax, rescale
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 mfma_bf16x8 pb[REP];
@@ -667,9 +683,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
+        if constexpr (STAMPS) { asm volatile("s_nop 0" ::"v"(o[REP - 1][DT - 1][3])); }
+        PA_MARK(4);                                         // P V^T issued and its last accumulator written
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile kt+1 has landed (this wave's part) ...
         __syncthreads();                                // ... and every wave's part after the barrier
+        PA_MARK(5);                                         // wait for the copies + barrier
     }
+    if constexpr (STAMPS) {
+        if (dbg && lane == 0) {
+            unsigned long long* d = dbg + ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            d[0] = st_t0; d[1] = wall_clock64();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[2 + i] = st_sum[i];
+        }
+    }
+#undef PA_MARK
     // ---- output: lane = query row fr, head dims dt*16 + g*4 .. +3 -> 8-byte stores ------------------------------
     if (qpos < T) {
 #pragma unroll
@@ -690,7 +718,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt, int vt_stride, const int* cu,
                               const int* slot_of_clip, int n_clips, int max_len, int heads, bf16_t* out,
-                              hipStream_t s) {
+                              hipStream_t s, unsigned long long* dbg) {
     if (n_clips <= 0 || max_len <= 0) return;
     const int mt = tuning().pa_mt;          // A/B knob: row tiles per wave
     const int form = tuning().pa_form;      // A/B knob: 2 = transposed-score form
@@ -699,6 +727,11 @@ void prefill_attention_launch(const bf16_t* qr, KVLayout cache, const bf16_t* vt
         const int hf = tuning().pa_order != 0 && cache.kv_heads == 8 ? 1 : 0;     // A/B knob; the XCD argument holds for 8 kv heads
         const dim3 grid = hf ? dim3(cache.kv_heads, n_clips, cdiv(max_len, 64)) : dim3(cdiv(max_len, 64), cache.kv_heads, n_clips);
         const bool vfrag = cache.vf != nullptr && tuning().pa_vfrag != 0;      // A/B knob; engines without the fragment image: V^T
+        if (dbg) {     // diagnostic build only (qasr_kernel_probe 5): [workgroup][wave][8] stamps
+            if (cache.hd != 128 || !vfrag) throw std::invalid_argument("prompt attention stamps: head_dim 128 with the fragment image only");
+            hipLaunchKernelGGL((prefill_attention2_kernel<128, true, true>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf, dbg);
+            return;
+        }
         if (cache.hd == 128) {
             if (vfrag) hipLaunchKernelGGL((prefill_attention2_kernel<128, true>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);
             else hipLaunchKernelGGL((prefill_attention2_kernel<128, false>), grid, dim3(256), 0, s, qr, cache, vt, vt_stride, cu, slot_of_clip, heads, out, scale, hf);

@@ -907,6 +907,7 @@ void Engine::batch_timings(float ms[5], int32_t* n_steps) {
 //   0: weight-streaming GEMVs of ONE decoder layer (qkv + o + gate/up + down weights, bf16)
 //   1: decode attention of ONE layer (K + V rows of every batch row at its current ctx)
 //   2: LM head (vocab x hidden bf16)
+//   3 / 4: prompt-pass q|k|v and gate|up GEMMs, 5: prompt attention of one layer (FLOPs instead of bytes)
 void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_launch) {
     if (!finalized_ || batch_ <= 0) throw std::runtime_error("kernel_probe needs a prepared batch");
     require_asr("kernel_probe");
@@ -947,6 +948,9 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         } else if (which == 4) {      // prompt-pass gate/up GEMM with the SwiGLU epilogue
             gemm_nt_swiglu(ADense{d_ph_.as<bf16_t>(), H, n_pos_, H}, probe_w.wgu, H, n_pos_, 2 * I, H,
                            EpiStoreBf16{d_pact_.as<bf16_t>(), I}, s);
+        } else if (which == 5) {      // prompt attention of layer 0 on the prepared batch (q rows and K / V images of the last prompt pass)
+            prefill_attention_launch(d_pqr_.as<bf16_t>(), kv, d_vt_.as<bf16_t>(), vt_stride_, d_p_cu_, d_p_slotclip_, batch_, max_len_,
+                                     cfg_.heads, d_pattn_.as<bf16_t>(), s);
         } else {
             run_lm_head(false, 0, batch_, s);
         }
@@ -1005,6 +1009,36 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                 "after sync %.2f | sweeps done %.2f | slot merge done %.2f | after sync %.2f | end %.2f | span %.2f\n", cnt,
                 acc[0] / cnt / 100, acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100,
                 acc[5] / cnt / 100, acc[6] / cnt / 100, (double)(t6 - t0) / 100);
+    }
+    if (which == 5 && tuning().pa_stamps) {
+        // diagnostic: one launch with per-wave phase sums (100 MHz wall clock); printed per query tile (= number of key tiles swept)
+        const int qt = (max_len_ + 63) / 64, nwg = qt * cfg_.kv_heads * batch_;
+        DevBuf d;
+        d.alloc((size_t)nwg * 4 * 8 * sizeof(unsigned long long));
+        QASR_HIP(hipMemsetAsync(d.p, 0, d.bytes, s));
+        prefill_attention_launch(d_pqr_.as<bf16_t>(), kv, d_vt_.as<bf16_t>(), vt_stride_, d_p_cu_, d_p_slotclip_, batch_, max_len_,
+                                 cfg_.heads, d_pattn_.as<bf16_t>(), s, d.as<unsigned long long>());
+        std::vector<unsigned long long> h((size_t)nwg * 4 * 8);
+        QASR_HIP(hipMemcpyAsync(h.data(), d.p, d.bytes, hipMemcpyDeviceToHost, s));
+        QASR_HIP(hipStreamSynchronize(s));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t i = 0; i < h.size(); i += 8) if (h[i]) { t0 = std::min(t0, h[i]); t1 = std::max(t1, h[i + 1]); }
+        // heavy-first grid (kv head, clip, query tile): blockIdx.z = qt - 1 - tile
+        for (int z = 0; z < qt; ++z) {
+            double acc[8] = {0}; int cnt = 0;
+            for (size_t w = (size_t)z * cfg_.kv_heads * batch_ * 4; w < (size_t)(z + 1) * cfg_.kv_heads * batch_ * 4; ++w) {
+                const unsigned long long* e = &h[w * 8];
+                if (!e[0]) continue;
+                acc[0] += (double)(e[0] - t0); acc[1] += (double)(e[1] - e[0]);
+                for (int k = 0; k < 6; ++k) acc[2 + k] += (double)e[2 + k];
+                ++cnt;
+            }
+            if (!cnt) continue;
+            fprintf(stderr, "[qasr] prompt attention stamps, query tile %d (%d key tiles), mean over %d waves, us: start %.2f | resident %.2f | prologue %.2f | "
+                    "copy issue %.2f | S^T %.2f | softmax %.2f | P V^T %.2f | copy wait + barrier %.2f\n", qt - 1 - z, qt - z, cnt, acc[0] / cnt / 100,
+                    acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100, acc[5] / cnt / 100, acc[6] / cnt / 100, acc[7] / cnt / 100);
+        }
+        fprintf(stderr, "[qasr] prompt attention stamps: span %.2f us\n", (double)(t1 - t0) / 100);
     }
     if (which == 0 && tuning().stamps_insitu) {
         // one real decode step (eager, all layers, cold weights) with layer 14's five launches stamped
@@ -1074,6 +1108,11 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     else if (which == 1) { for (int b = 0; b < rows; ++b) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)ctx[b]; }
     else if (which == 3) bytes = 2.0 * (double)n_pos_ * nh * hd * H;          // FLOPs for the GEMM probes
     else if (which == 4) bytes = 2.0 * (double)n_pos_ * 2 * I * H;
+    else if (which == 5) {      // causal FLOPs: per clip and head 4 hd sum_t (t + 1) = 2 hd T (T + 1)
+        std::vector<int> cu(batch_ + 1);
+        QASR_HIP(hipMemcpy(cu.data(), d_p_cu_, (batch_ + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        for (int b = 0; b < batch_; ++b) { const double T = cu[b + 1] - cu[b]; bytes += 2.0 * hd * T * (T + 1.0) * cfg_.heads; }
+    }
     else bytes = wbytes * (double)cfg_.vocab * H;
     *bytes_per_launch = bytes;
 }

@@ -26,7 +26,7 @@ const Entry kEntries[] = {
     {"graph_steps", &Tuning::graph_steps, {1, 2, 4, 8, -1}, false}, {"use_graph", &Tuning::use_graph, {0, 1, -1}, false},
     {"device_sampler", &Tuning::device_sampler, {0, 1, -1}, false},
     {"da_stamps", &Tuning::da_stamps, {0, 1, -1}, true}, {"gemv_stamps", &Tuning::gemv_stamps, {0, 1, -1}, true},
-    {"stamps_insitu", &Tuning::stamps_insitu, {0, 1, -1}, true},
+    {"stamps_insitu", &Tuning::stamps_insitu, {0, 1, -1}, true}, {"pa_stamps", &Tuning::pa_stamps, {0, 1, -1}, true},
 };
 
 bool value_allowed(const Entry& e, int v) {

@@ -38,7 +38,7 @@ struct Tuning {
     int use_graph = 1;       // 0: issue every decode step eagerly (no hipGraph replay)
     int device_sampler = 1;  // non-default decoding options: 1 pickNextToken on the device (no host round trip per step) | 0 logits to the host,
                              // csrc/sampler.cpp picks (the reference's own structure)
-    int da_stamps = 0, gemv_stamps = 0, stamps_insitu = 0;   // diagnostics of qasr_kernel_probe (make DIAG=1 builds)
+    int da_stamps = 0, gemv_stamps = 0, stamps_insitu = 0, pa_stamps = 0;   // diagnostics of qasr_kernel_probe (make DIAG=1 builds)
     unsigned epoch = 0;
 };
 
