@@ -76,6 +76,23 @@ def test_batches_in_flight_equal_single_engine(sd, single, devices):
         dp.close()
 
 
+def test_a_failed_batch_in_flight_surfaces_at_collect(sd):
+    """The engine's status and message come back through qasr_dp_collect; the lane is free again afterwards and the next batch runs."""
+    dp = Qwen3ASRDataParallel.from_state_dict(sd, [0, 0], preset="tiny", max_batch=2, max_audio_seconds=2, max_new_tokens=8)
+    try:
+        good = _clips(2)
+        t_bad = dp.submit(_clips(1) + [np.zeros(16000 * 3, np.float32)], max_tokens=4)      # a clip beyond the engines' capacity
+        t_good = dp.submit(good, max_tokens=4, ignore_eos=True)
+        with pytest.raises(QasrError, match="qasr error 5"):
+            dp.collect(t_bad)
+        got = dp.collect(t_good)
+        assert [len(g) for g in got] == [4, 4]
+        t = dp.submit(good, max_tokens=4, ignore_eos=True)                                    # the lane that failed takes the next batch
+        assert dp.collect(t) == got
+    finally:
+        dp.close()
+
+
 def test_destroy_with_a_batch_in_flight(sd):
     dp = Qwen3ASRDataParallel.from_state_dict(sd, [0, 0], preset="tiny", max_batch=4, max_audio_seconds=4, max_new_tokens=12)
     clips = _clips(4)
