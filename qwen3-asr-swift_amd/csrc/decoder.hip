@@ -13,6 +13,7 @@
 //   decode activations are [batch row][features]
 #include "engine.h"
 #include "dec_sampler.h"
+#include "dec_chain.h"
 #include "dec_gemv_wide.h"
 #include <algorithm>
 #include <cmath>
@@ -269,6 +270,8 @@ void Engine::finalize_decoder() {
     d_dqkv_.alloc((size_t)B * nh * hd * 2);
     d_dattn_.alloc((size_t)B * nq * 2);
     d_dact_.alloc((size_t)B * I * 2);
+    d_chain_ctr_.alloc(CHAIN_CTR_BYTES);
+    QASR_HIP(hipMemsetAsync(d_chain_ctr_.p, 0, CHAIN_CTR_BYTES, stream_));
     d_logits_.alloc((size_t)B * cfg_.vocab * sizeof(float));
     n_parts_ = decw_.quant ? lm_head_q_parts(cfg_.vocab, H, cfg_.bits) : lm_head_parts(cfg_.vocab, H);
     const int parts_cap = std::max(n_parts_, decode_gemv_blocks(DEC_EPI_LOGITS, cfg_.vocab));
@@ -563,6 +566,10 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     bf16_t* at = d_dattn_.as<bf16_t>() + (size_t)r0 * nq;
     bf16_t* act = d_dact_.as<bf16_t>() + (size_t)r0 * I;
     const GreedyState gs = greedy_rows(r0);
+    // chain > 0: a layer's linears run as one persistent launch (dec_chain.hip) wherever it has an instantiation: the float 0.6B geometry,
+    // the whole batch in one row group (the arrival counters belong to one step of one engine), up to 32 rows
+    const int chain = (!decw_.quant && r0 == 0 && !stamp_buf_ && decode_chain_supported(H, nq, I, nh * hd, nr)) ? tuning().chain : 0;
+    if (chain) decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
         KVLayout kv{kcache_[l]->as<bf16_t>(), nullptr, max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
@@ -573,12 +580,29 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         const size_t dbg_stride = (size_t)512 * 16 * 8;
         DecGemvArgs a{};
         auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) { decode_gemv(epi, a, qi, norm_w, h, s); };
-        a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
-        decode_gemv_set_debug(dbg);
-        gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
+        if (chain < 3 || l == 0) {         // chain 3: layer l's q|k|v came out of layer l - 1's launch
+            a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
+            decode_gemv_set_debug(dbg);
+            gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
+        }
         const RopeRows rr = rope_rows(r0);
         decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
                                 rr.cos_rows, rr.sin_rows, kv, at, s, dbg ? dbg + 4 * dbg_stride : nullptr);
+        if (chain) {
+            const bool last = l + 1 == cfg_.dec_layers;
+            const DecLayerW& Ln = decw_.layers[last ? l : l + 1];
+            DecChainArgs c{at, L.wo_p, x, L.ln2, L.wgu_p, act, L.wdown_p, Ln.ln1, Ln.wqkv_p, qkv, nr, cfg_.rms_eps,
+                           d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_};
+            int phases = CHAIN_O | CHAIN_GU;
+            if (chain >= 2) phases |= CHAIN_DOWN;
+            if (chain >= 3 && !last) phases |= CHAIN_QKV;
+            decode_chain_launch(phases, c, s);
+            if (chain == 1) {
+                a.B = nr; a.W = L.wdown; a.Wp = L.wdown_p; a.X = act; a.N = H; a.K = I; a.out = x;
+                gemv(DEC_EPI_RESID, L.down_q, nullptr);
+            }
+            continue;
+        }
         a.W = L.wo; a.Wp = L.wo_p; a.X = at; a.N = H; a.K = nq; a.out = x;
         decode_gemv_set_debug(dbg ? dbg + dbg_stride : nullptr);
         gemv(DEC_EPI_RESID, L.o_q, nullptr);
@@ -892,6 +916,8 @@ void Engine::batch_tokens(int32_t* tokens, int32_t* lens) {
     int err = 0;
     QASR_HIP(hipMemcpyAsync(&err, d_err_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_));
     QASR_HIP(hipStreamSynchronize(stream_));
+    if (err & CHAIN_ERR_TIMEOUT)
+        throw HipError("decode chain: an in-launch hand-off wait gave up (a workgroup of the persistent grid was not resident within the budget); tokens are not valid");
     if (err) throw HipError("greedy decode saw a non-finite best logit (NaN / inf in the weights or activations); tokens are not valid");
 }
 

@@ -219,6 +219,10 @@ void Engine::batch_stage(const float* const* pcm, const size_t* n, size_t B) {
         QASR_HIP(hipEventCreateWithFlags(&ev_stage_done_, hipEventDisableTiming));
         h_pcm2_.alloc(h_pcm_.bytes);
         h_meta2_.alloc(h_meta_.bytes);
+        // The batch already running was issued before this event existed, so its batch_run could not record it after the log-mel:
+        // record it now, at the tail of everything that batch has queued (later than needed, never earlier).  Without this the wait
+        // below is on a never-recorded event, i.e. no wait, and the copies could land in d_pcm_ / d_meta_ under a log-mel still queued.
+        if (run_issued_) QASR_HIP(hipEventRecord(ev_mel_done_, stream_));
     }
     staged_valid_ = false;
     QASR_HIP(hipStreamSynchronize(copy_stream_));  // the previous staged batch's copies have left the second pinned buffer

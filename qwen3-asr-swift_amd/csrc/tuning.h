@@ -14,6 +14,9 @@ struct Tuning {
     int gemv_partial = 1;    // fewer than 16 batch rows: norm GEMVs skip the normalisation of rows past the end (own instantiation) | 0 off
     int gemv_earlyw = 1;     // at most 8 batch rows: the weight stream requested without waiting for the activation rows | 0 after them (as at 16+ rows)
     int gemv_wide = 1;       // K = 6144 (1.7B down-projection): 1 two-phase LDS image, weights in registers (dec_gemv_wide.hip) | 0 generic kernel
+    int chain = 0;           // decode layer's linears as one persistent launch with in-launch hand-offs (dec_chain.hip): 0 five launches per layer |
+                             // 1 o-proj -> gate|up | 2 ... -> down | 3 ... -> the next layer's q|k|v (two launches per layer: attention + chain)
+    int chain_nt = 0;        // chain weight stream: 1 non-temporal loads | 0 default cache policy
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
     int da_spec = 3;         // K/V requests issued before ctx_len is known: 0 none | 1 each wave's first chunk (no byte past the context at 256+ keys) |
                              // 2 every chunk of the first round (1.26 x the algorithmic bytes at 32 x 30 s) | 3 = 2 up to 8 batch rows, 1 above

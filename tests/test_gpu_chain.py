@@ -1,0 +1,63 @@
+"""The decode layer's linears as one persistent launch with in-launch hand-offs (csrc/dec_chain.hip, tuning knob `chain`) against
+the five-launch layer it replaces, through the C ABI.  Both run the same arithmetic per 16-row group (same k order over the waves,
+same cross-wave order, same norm sums), so the bar is BIT equality: logits of forced steps at one row, tokens at every batch size
+that selects another instantiation (1 and 8 rows: one batch tile, partly empty; 16: one full tile; 17: the second row group nearly
+empty; 32: both full).  Three decoder layers at the 0.6B widths: with chain = 3 the first two launches carry the next layer's q|k|v,
+the last one does not.  The parity of the five-launch layer itself against the oracle is tests/test_gpu_decoder.py / test_gpu_bench_shapes.py."""
+import dataclasses
+import numpy as np
+import pytest
+import torch
+from oracle import config as C, precision as P
+from qasr import synth
+import gpu_util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    t = dataclasses.replace(C.TEXT_SMALL, layers=3)
+    sd = synth.synth_state_dict(dataclasses.replace(C.AUDIO_SMALL, layers=1), t, seed=0, init="stress")
+    e = gpu_util.Engine("0.6B", max_batch=32, max_audio_seconds=4, max_new_tokens=16, enc_layers=1, dec_layers=3)
+    e.load_state_dict(sd)
+    yield e
+    e.set_tuning("chain", 0)
+    e.set_tuning("chain_nt", 0)
+    e.close()
+
+
+def _run(eng, clips, emb, forced):
+    first = eng.prefill_logits(emb)
+    steps = eng.decode_forced(forced)
+    return first, steps, [eng.transcribe_batch(clips[:b], max_tokens=7, ignore_eos=True) for b in (1, 8, 16, 17, 32)]
+
+
+@pytest.mark.parametrize("nt", [0, 1], ids=["default-policy", "nt-weights"])
+def test_chain_equals_five_launch_layer_bit_for_bit(eng, nt):
+    emb = P.bf16_round(torch.randn(33, 1024, generator=torch.Generator().manual_seed(7)) * 0.5).numpy()
+    clips = [synth.synth_waveform(k, 1.0 + 0.17 * (k % 5)) for k in range(32)]
+    eng.set_tuning("chain", 0)
+    eng.set_tuning("chain_nt", nt)
+    base = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
+    assert len({tuple(t) for t in base[2][-1]}) > 1            # the rows do differ
+    for mode in (1, 2, 3):
+        eng.set_tuning("chain", mode)
+        got = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
+        assert np.array_equal(got[0], base[0]), mode
+        assert np.array_equal(got[1], base[1]), (mode, float(np.abs(got[1] - base[1]).max()))
+        for b, (g, w) in zip((1, 8, 16, 17, 32), zip(got[2], base[2])):
+            assert g == w, (mode, b)
+    eng.set_tuning("chain", 0)
+
+
+def test_chain_natural_eos_and_reruns(eng):
+    """Replayed graphs: the counters are zeroed by a memset node at the start of every step, so any number of steps and reruns count
+    from zero; rows that finish early (natural EOS under the stress weights, or the 448-token cap) keep running through the launch."""
+    clips = [synth.synth_waveform(40 + k, 0.8 + 0.1 * (k % 7)) for k in range(24)]
+    eng.set_tuning("chain", 0)
+    want = eng.transcribe_batch(clips, max_tokens=16)
+    eng.set_tuning("chain", 3)
+    for _ in range(3):
+        assert eng.transcribe_batch(clips, max_tokens=16) == want
+    eng.set_tuning("chain", 0)
