@@ -10,7 +10,7 @@ namespace qasr {
 
 enum DecChainPhase { CHAIN_O = 1, CHAIN_GU = 2, CHAIN_DOWN = 4, CHAIN_QKV = 8 };
 
-constexpr int CHAIN_SEAMS = 3;            // o -> gate|up, gate|up -> down, down -> next q|k|v
+constexpr int CHAIN_SEAMS = 4;            // o -> gate|up, gate|up -> down, down -> next q|k|v; block 3: q|k|v -> attention, one counter per kv head (dec_qa.hip)
 constexpr int CHAIN_SHARDS = 8;           // arrival counters are sharded over 8 lines (fan-in of up to 192 producers)
 constexpr int CHAIN_SHARD_WORDS = 32;     // one 128-byte line per shard
 constexpr size_t CHAIN_CTR_BYTES = (size_t)CHAIN_SEAMS * CHAIN_SHARDS * CHAIN_SHARD_WORDS * sizeof(unsigned);
@@ -32,7 +32,28 @@ struct DecChainArgs {
     unsigned* ctr;          // CHAIN_CTR_BYTES, zeroed at the start of every decode step (decode_chain_reset)
     unsigned epoch;         // chain launches earlier in this step: the counters count up through a step
     int* err;               // device word; CHAIN_ERR_TIMEOUT is or-ed in when a wait gives up
+    unsigned long long* dbg = nullptr;   // diagnostic: [256][32] phase stamps of this launch (qasr_kernel_probe 6), null in product launches
 };
+
+// q|k|v projection + decode attention of one layer as one launch (dec_qa.hip): the K / V stream is requested before the projection runs
+struct DecQaArgs {
+    const bf16_t* x;        // [B][H] layer input (written by the previous launch)
+    const bf16_t* ln1;      // [H]
+    const bf16_t* wqkv_p;   // fragment-major [nqkv][H]
+    bf16_t* qkv;            // [B][nqkv] hand-off rows (write-through)
+    const int* ctx_len;     // [B]
+    const bf16_t *qn_w, *kn_w;
+    const float *rope_cos, *rope_sin;   // per-row copies of the current position's table rows [B][hd / 2]
+    KVLayout cache;
+    bf16_t* out;            // [B][heads * hd]
+    int B;
+    float eps, scale;       // RMSNorm epsilon; 1 / sqrt(head_dim)
+    unsigned* ctr;          // the chain's counter block (block 3 is used here)
+    unsigned epoch;         // layer index
+    int* err;
+};
+bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_ctx);
+void decode_qa_launch(const DecQaArgs& a, hipStream_t s);
 
 // true when the geometry has a chain instantiation (0.6B decoder: hidden 1024, 16 x 128 query dims, inter 3072, q|k|v 4096 rows;
 // 1..32 batch rows) and the device has a CU for every workgroup of the persistent grid

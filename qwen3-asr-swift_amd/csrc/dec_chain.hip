@@ -21,154 +21,14 @@
 // handed-off bytes is an sc1 load into registers (buffer_load_dwordx4 sc1 / global_load_dwordx2 sc1): no fences.  Counters are zeroed by a
 // memset node at the start of each decode step and count up through the step's 28 launches (epoch = layer index).  Every spin is bounded by
 // a wall-clock budget; a wait that gives up sets CHAIN_ERR_TIMEOUT in *err and the whole workgroup leaves the kernel (the host reports it).
-#include "dec_chain.h"
-#include "dec_epilogue.h"
+#include "dec_chain_dev.h"
 #include <mutex>
 #include <map>
 
 namespace qasr {
 namespace {
 
-constexpr int CT = 512, CWAVES = 8;
-constexpr int CH_H = 1024, CH_NQ = 2048, CH_I = 3072, CH_NQKV = 4096;
-constexpr int CH_GRID = 256;
-constexpr unsigned long long CH_SPIN_TICKS = 20000000ull;          // 200 ms of the 100 MHz wall clock
-
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-// dynamic LDS carve (bytes, all multiples of 16)
-constexpr int L_NORM = 0;                                          // ln2 | next ln1: 2 x 2 KiB
-constexpr int L_FLAG = 4096;
-constexpr int L_X = 4224;                                          // activation image [rows][2 K + 16]
-constexpr int L_XMAX = 16 * (2 * CH_I + 16);                       // down: 98,560 B (gate|up / q|k|v with 32 rows: 66,048)
-constexpr int L_RED = L_X + L_XMAX;                                // cross-wave partial sums [7][NT * NBU][256] f32
-constexpr int L_TOTAL = L_RED + 7 * 4 * 1024;                      // 131,456 B: one workgroup per CU
-
-template <bool NTW>
-__device__ __forceinline__ uint4 ld_weight(const bf16_t* p) {
-    if constexpr (NTW) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-        return make_uint4(v.x, v.y, v.z, v.w);
-    } else {
-        return *reinterpret_cast<const uint4*>(p);
-    }
-}
-
-__device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);       // aux 16 = sc1
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ uint2 ld8_sc1(const bf16_t* p) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint2((unsigned)v, (unsigned)(v >> 32));
-}
-__device__ __forceinline__ void st8_sc1(bf16_t* p, uint2 v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// wave 0, after its write-through stores: drain, then one lane arrives
-__device__ __forceinline__ void seam_signal(unsigned* ctr, int seam, int unit) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(ctr + (seam * CHAIN_SHARDS + (unit & (CHAIN_SHARDS - 1))) * CHAIN_SHARD_WORDS, 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// every thread of the workgroup calls this; wave 0 polls the seam's shards.  false: the wait gave up (uniform over the workgroup)
-__device__ __forceinline__ bool seam_wait(const unsigned* ctr, int seam, unsigned target, int* err, int* s_flag) {
-    if (threadIdx.x < 64) {
-        const unsigned* c = ctr + (seam * CHAIN_SHARDS + (threadIdx.x & (CHAIN_SHARDS - 1))) * CHAIN_SHARD_WORDS;
-        const unsigned long long t0 = wall_clock64();
-        bool ok;
-        for (;;) {
-            const unsigned v = threadIdx.x < CHAIN_SHARDS ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-            ok = __builtin_amdgcn_ballot_w64(v < target) == 0;
-            if (ok || wall_clock64() - t0 > CH_SPIN_TICKS) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (threadIdx.x == 0) {
-            *s_flag = ok ? 1 : 0;
-            if (!ok) atomicOr(err, CHAIN_ERR_TIMEOUT);
-        }
-    }
-    __syncthreads();
-    return *s_flag != 0;
-}
-
-// One unit with its weight fragments already in registers: acc[t][b] (valid on wave 0 afterwards) = [rmsnorm](X rows) . W^T for NT weight
-// tiles and NBU batch tiles.  xr[p][i] = chunk (scol + 32 i) of row (16 p + srow), zero for rows past the batch.
-template <int NT, int NBU, int KSW, bool NORM>
-__device__ __forceinline__ void chain_mma(const uint4 (&w)[NT][KSW], const uint4 (&xr)[NBU][KSW], const char* s_normw, float eps, char* s_x,
-                                          float* s_red, f32x4 (&acc)[NT][NBU]) {
-    constexpr int K = KSW * CWAVES * 32, XSTRIDE = 2 * K + 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
-    const int srow = tid >> 5, scol = tid & 31;
-#pragma unroll
-    for (int p = 0; p < NBU; ++p) {
-        char* xrow = s_x + (size_t)(p * 16 + srow) * XSTRIDE + scol * 16;
-        if constexpr (NORM) {
-            float ss = 0.0f;
-#pragma unroll
-            for (int i = 0; i < KSW; ++i) {
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[p][i]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
-            }
-            ss = lane_sum<32>(ss);
-            const float inv = rsqrtf(ss / (float)K + eps);
-#pragma unroll
-            for (int i = 0; i < KSW; ++i) {
-                const uint4 nw = *reinterpret_cast<const uint4*>(s_normw + (scol + i * 32) * 16);
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[p][i]);
-                const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
-                uint4 o;
-                bf16_t* oe = reinterpret_cast<bf16_t*>(&o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) oe[j] = f32_to_bf16(bf16_to_f32(we[j]) * bf16_round(bf16_to_f32(e[j]) * inv));
-                *reinterpret_cast<uint4*>(xrow + i * 32 * 16) = o;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < KSW; ++i) *reinterpret_cast<uint4*>(xrow + i * 32 * 16) = xr[p][i];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int b = 0; b < NBU; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < KSW; ++i) {
-        const int kb = ((wave + CWAVES * i) * 32 + fc * 8) * 2;
-#pragma unroll
-        for (int b = 0; b < NBU; ++b) {
-            const uint4 xf = *reinterpret_cast<const uint4*>(s_x + (size_t)(b * 16 + fr) * XSTRIDE + kb);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, w[t][i]), __builtin_bit_cast(mfma_bf16x8, xf),
-                                                                    acc[t][b], 0, 0, 0);
-        }
-    }
-    // cross-wave sums in the fixed order wave 0 + 1 + ... + 7
-    if (wave > 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int b = 0; b < NBU; ++b)
-                *reinterpret_cast<f32x4*>(&s_red[((size_t)(wave - 1) * NT * NBU + t * NBU + b) * 256 + lane * 4]) = acc[t][b];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int b = 0; b < NBU; ++b)
-#pragma unroll
-                for (int wv = 0; wv < CWAVES - 1; ++wv)
-                    acc[t][b] += *reinterpret_cast<const f32x4*>(&s_red[((size_t)wv * NT * NBU + t * NBU + b) * 256 + lane * 4]);
-    }
-}
+using namespace chain_dev;
 
 __device__ __forceinline__ uint2 resid_add(uint2 r, const f32x4& acc) {
     float4 v = unpack_bf16x4(r);
@@ -176,7 +36,9 @@ __device__ __forceinline__ uint2 resid_add(uint2 r, const f32x4& acc) {
     return pack_bf16x4(v);
 }
 
-template <int PH, int NB, bool NTW>
+// ST: diagnostic instantiation (qasr_kernel_probe 6): thread 0 of every workgroup stamps the 100 MHz clock into a.dbg[wg * 32 + i]:
+//   0 entry | O: 1 staged 2 summed 3 signalled | GU: 4 wait over 5 rows in 6 staged 7 summed 8 signalled | DOWN: 9..13 | QKV: 14..18 (18 = stored)
+template <int PH, int NB, bool NTW, bool ST>
 __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
@@ -191,6 +53,10 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
     float* s_red = reinterpret_cast<float*>(dsm + L_RED);
     int* s_flag = reinterpret_cast<int*>(dsm + L_FLAG);
     const int B = a.B;
+    unsigned long long* st = ST ? a.dbg + (long)wg * 32 : nullptr;
+#define CH_STAMP(i) do { if constexpr (ST) { if (tid == 0) st[i] = wall_clock64(); } } while (0)
+#define CH_ROWS_IN(i) do { if constexpr (ST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) st[i] = wall_clock64(); } } while (0)
+    CH_STAMP(0);
 
     // ---- requests: norm weights (oldest: they come back first), the first phase's activation rows, then EVERY phase's weight tiles ----
     // one unconditional load per thread (threads 256.. read duplicates): a load under a divergent branch is waited for at the join
@@ -226,10 +92,11 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
             for (int i = 0; i < 8; ++i) xo[0][i] = make_uint4(0, 0, 0, 0);
         }
         f32x4 acc[1][1];
-        chain_mma<1, 1, 8, false>(wO, xo, nullptr, 0.f, s_x, s_red, acc);
+        chain_mma<1, 1, 8, false, ST>(wO, xo, nullptr, 0.f, s_x, s_red, acc, st + 1);
         if (wave == 0) {
             if (r0 + fr < B) st8_sc1(xout, resid_add(rsd, acc[0][0]));
             seam_signal(a.ctr, 0, wg);
+            CH_STAMP(3);
         }
     } else {
         if (has_down) {
@@ -253,6 +120,7 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
     // ---- phase GU: act[rows][16 cols] = swiglu(rmsnorm(x) . Wg^T, rmsnorm(x) . Wu^T) -------------------------------------------------
     if (has_gu) {
         if (!seam_wait(a.ctr, 0, (a.epoch + 1) * (8 * NB), a.err, s_flag)) return;
+        CH_STAMP(4);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, 32 * CH_H * 2, 0x00020000);
         uint4 xr[NB][4];
 #pragma unroll
@@ -268,8 +136,9 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xr[p][i] = make_uint4(0, 0, 0, 0);
             }
+        CH_ROWS_IN(5);
         f32x4 acc[2][NB];
-        chain_mma<2, NB, 4, true>(wB, xr, dsm + L_NORM, a.eps, s_x, s_red, acc);
+        chain_mma<2, NB, 4, true, ST>(wB, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 6);
         if (wave == 0) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -284,12 +153,14 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
                 }
             }
             seam_signal(a.ctr, 1, wg);
+            CH_STAMP(8);
         }
     }
 
     // ---- phase DOWN: x[rows][16 cols] += act[rows] . Wd[tile]^T --------------------------------------------------------------------
     if (has_down) {
         if (!seam_wait(a.ctr, 1, (a.epoch + 1) * 24, a.err, s_flag)) return;
+        CH_STAMP(9);
         const int du = wg - DOWN0, dt = du & 63, r0 = (du >> 6) * 16;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.act, 0, 32 * CH_I * 2, 0x00020000);
         uint4 xr[1][12];
@@ -305,17 +176,20 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) xr[0][i] = make_uint4(0, 0, 0, 0);
         }
+        CH_ROWS_IN(10);
         f32x4 acc[1][1];
-        chain_mma<1, 1, 12, false>(wAD, xr, nullptr, 0.f, s_x, s_red, acc);
+        chain_mma<1, 1, 12, false, ST>(wAD, xr, nullptr, 0.f, s_x, s_red, acc, st + 11);
         if (wave == 0) {
             if (r0 + fr < B) st8_sc1(xout, resid_add(rsd, acc[0][0]));
             seam_signal(a.ctr, 2, du);
+            CH_STAMP(13);
         }
     }
 
     // ---- phase QKV: the next layer's q|k|v[rows][16 cols] = rmsnorm(x) . Wqkv[tile]^T (read by the next launch: plain stores) --------
     if constexpr (P_QKV) {
         if (!seam_wait(a.ctr, 2, (a.epoch + 1) * (8 * NB), a.err, s_flag)) return;
+        CH_STAMP(14);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, 32 * CH_H * 2, 0x00020000);
         uint4 xr[NB][4];
 #pragma unroll
@@ -331,8 +205,9 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xr[p][i] = make_uint4(0, 0, 0, 0);
             }
+        CH_ROWS_IN(15);
         f32x4 acc[1][NB];
-        chain_mma<1, NB, 4, true>(wC, xr, dsm + L_NORM + 2048, a.eps, s_x, s_red, acc);
+        chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM + 2048, a.eps, s_x, s_red, acc, st + 16);
         if (wave == 0) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -341,8 +216,11 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
                     *reinterpret_cast<uint2*>(a.qkv + (long)row * CH_NQKV + wg * 16 + fc * 4) =
                         pack_bf16x4(make_float4(acc[0][b][0], acc[0][b][1], acc[0][b][2], acc[0][b][3]));
             }
+            CH_STAMP(18);
         }
     }
+#undef CH_STAMP
+#undef CH_ROWS_IN
 }
 
 int device_cus() {
@@ -361,7 +239,13 @@ int device_cus() {
 
 template <int PH, int NB, bool NTW>
 void chain_go(const DecChainArgs& a, hipStream_t s) {
-    auto kern = decode_chain_kernel<PH, NB, NTW>;
+    if (a.dbg) {                       // diagnostic launch: default-policy weight loads only
+        auto kst = decode_chain_kernel<PH, NB, false, true>;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kst), L_TOTAL);
+        hipLaunchKernelGGL(kst, dim3(CH_GRID), dim3(CT), L_TOTAL, s, a);
+        return;
+    }
+    auto kern = decode_chain_kernel<PH, NB, NTW, false>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L_TOTAL);
     hipLaunchKernelGGL(kern, dim3(CH_GRID), dim3(CT), L_TOTAL, s, a);
 }

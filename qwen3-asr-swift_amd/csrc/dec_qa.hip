@@ -1,0 +1,343 @@
+// dec_qa.hip -- one decoder layer's q|k|v projection and decode attention as ONE launch (declarations: dec_chain.h).
+//
+// Why: the decode attention (dec_attention.hip) spends 10 of its 15 us waiting for its K / V bytes (61 MB per launch at 32 x 30 s), and those
+// bytes depend on nothing the layer computes -- only the token's own q / k / v rows do.  As a separate launch the stream cannot start before
+// the q|k|v projection's launch has ended (5 us + a kernel boundary).  Here every workgroup first requests the projection's operands, then the
+// whole first round of its attention unit's K / V chunks into registers, runs the projection while they fly, hands the 32 x 4096 projected
+// rows over inside the launch (dec_chain_dev.h: write-through stores, one arrival counter per kv head, sc1 loads) and sweeps when both are in.
+//
+// Grid: 256 workgroups x 512 threads, one per CU.  Workgroup g projects weight-row tile g (16 of the 4096 q|k|v columns, all batch rows) and then
+// owns attention unit (batch row g / 8, kv head g % 8).  The arithmetic is decode_gemv2_kernel's and decode_attention_mfma_kernel's, chunk for
+// chunk and wave for wave: same bits as the two launches (tests/test_gpu_chain.py).
+//
+// vmcnt is one in-order counter for loads and stores (gfx9): a wave that drains its stores, or waits for a poll, waits for every older
+// load of its own.  So wave 0 -- epilogue stores, drain, signal, poll -- keeps no K / V request in flight until the hand-off is over: its
+// early requests all read ONE cached 16 bytes (so that every wave runs the same unconditional request code and hipcc's counted waits stay
+// exact), and it requests its real chunks after the poll.  Waves 1..7 hold their chunks from the start.
+#include "dec_chain_dev.h"
+#include "dec_rope.h"
+#include <mutex>
+
+namespace qasr {
+namespace {
+
+using namespace chain_dev;
+
+constexpr int QA_HD = 128, QA_HEADS = 16, QA_KVH = 8, QA_NQKV = 4096, QA_UNR = 2;
+
+template <int HD>
+__device__ __forceinline__ long qa_vfrag_index(int key, int d) {       // = vfrag_index of dec_attention.hip
+    constexpr int DT = HD / 16;
+    const int kb = key >> 5, r = key & 31, half = r >> 4, g = (r & 15) >> 2, j = r & 3;
+    return (((long)kb * DT + (d >> 4)) * 64 + (d & 15) + 16 * g) * 8 + half * 4 + j;
+}
+
+template <int NB>
+__global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
+    constexpr int HD = QA_HD, REP = 2, KS = HD / 32, DT = HD / 16, HALF = HD / 2, WAVES = CWAVES, UNR = QA_UNR;
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4, fc = g;
+    const int srow = tid >> 5, scol = tid & 31;
+    const int wg = blockIdx.x;
+    const int B = a.B;
+    const int b = wg >> 3, kvh = wg & 7;
+    const bool has_att = b < B;
+    const int bq = has_att ? b : 0;
+    char* s_x = dsm + L_X;
+    float* s_red = reinterpret_cast<float*>(dsm + L_RED);
+    int* s_flag = reinterpret_cast<int*>(dsm + L_FLAG);
+    const KVLayout cache = a.cache;
+
+    // ---- requests, oldest first: context length, norm weights, activation rows, weight tile, then the K / V chunks ------------------
+    int pos = a.ctx_len[bq];
+    const uint4 nw = reinterpret_cast<const uint4*>(a.ln1)[tid & 127];
+    uint4 xr[NB][4];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        const int row = p * 16 + srow;
+        const bf16_t* xp = a.x + (long)(row < B ? row : 0) * CH_H + scol * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[p][i] = *reinterpret_cast<const uint4*>(xp + i * 32 * 8);
+    }
+    uint4 wC[1][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wC[0][i] = *reinterpret_cast<const uint4*>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
+
+    const bf16_t* kb = cache.k + cache.off(bq, kvh, 0) + g * 8;
+    const bf16_t* vfb = cache.vf + cache.off(bq, kvh, 0) + lane * 8;
+    const bf16_t* kdummy = cache.k + cache.off(bq, kvh, 0);
+    const int max_chunk = cache.max_ctx / 32 - 1;
+    pos = has_att ? __builtin_amdgcn_readfirstlane(pos) : 1;         // wave-uniform by construction: scalar loop bounds below
+    const int nchunks = (pos + 31) >> 5;
+    uint4 kreg[UNR][2 * KS], vreg[UNR][DT];
+    const bool dummy = wave == 0 || !has_att;                         // see the file header
+    int ch_early[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        int ch = wave + u * WAVES;
+        ch = ch < nchunks - 1 ? ch : nchunks - 1;                     // chunks past the context re-read the last one (cache hits), skipped in the sweep
+        ch_early[u] = ch < max_chunk ? ch : max_chunk;
+    }
+    // K chunks now; the V chunks once the activation rows have left their registers for LDS (register budget: 256 per thread)
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const bf16_t* kr = kb + ((long)ch_early[u] * 32 + fr) * HD;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(dummy ? kdummy : kr + (long)h * 16 * HD + ks * 32);
+    }
+    if (tid < 128) reinterpret_cast<uint4*>(dsm + L_NORM)[tid] = nw;
+    __syncthreads();
+
+    // ---- q|k|v projection of tile wg for every batch row ------------------------------------------------------------------------------
+#pragma unroll
+    for (int p = 0; p < NB; ++p)
+        if (p * 16 + srow >= B) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xr[p][i] = make_uint4(0, 0, 0, 0);
+        }
+    {
+        f32x4 acc[1][NB];
+        auto issue_v = [&]() {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                    vreg[u][dt] = *reinterpret_cast<const uint4*>(dummy ? kdummy : vfb + ((long)ch_early[u] * DT + dt) * 512);
+        };
+        chain_mma<1, NB, 4, true>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, nullptr, issue_v);
+        if (wave == 0) {
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const int row = p * 16 + fr;
+                if (row < B)
+                    st8_sc1(a.qkv + (long)row * QA_NQKV + wg * 16 + fc * 4,
+                            pack_bf16x4(make_float4(acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3])));
+            }
+            // tile -> kv head it feeds: q columns (tiles 0..127, 16 per kv head), then k (8 per head), then v
+            const int grp = wg < 128 ? wg >> 4 : (wg < 192 ? (wg - 128) >> 3 : (wg - 192) >> 3);
+            seam_signal(a.ctr, 3, grp);
+        }
+    }
+    if (!has_att) return;
+    if (!seam_wait_n(a.ctr + (3 * CHAIN_SHARDS + kvh) * CHAIN_SHARD_WORDS, 1, (a.epoch + 1) * 32, a.err, s_flag)) return;
+
+    // ---- attention unit (b, kvh): decode_attention_mfma_kernel's body with the first round of K / V already requested -----------------
+    auto issue = [&](int chunk0, int limit) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            int ch = chunk0 + u * WAVES;
+            if (ch >= limit) continue;
+            ch = ch < max_chunk ? ch : max_chunk;
+            const bf16_t* kr = kb + ((long)ch * 32 + fr) * HD;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                vreg[u][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch * DT + dt) * 512);
+        }
+    };
+    if (wave == 0) issue(0, nchunks);
+    bf16_t* s_q = reinterpret_cast<bf16_t*>(s_x);                                       // [WAVES][REP][HD]
+    float* s_o = reinterpret_cast<float*>(s_x + WAVES * REP * HD * 2);                  // [WAVES][REP][HD]
+    float* s_m = s_o + WAVES * REP * HD;                                                // [WAVES][REP]
+    float* s_l = s_m + WAVES * REP;
+    float* s_new = s_l + WAVES * REP;                                                   // [REP]
+    float* s_vn = s_new + REP;                                                          // [HD]
+    // the token's own rows: handed-off bytes -> sc1 loads, one dword (two elements) per lane, then a lane permute puts element `lane`
+    // and element `lane + 64` on every lane like the two-byte loads of the stand-alone kernel
+    const bf16_t* row = a.qkv + (long)b * QA_NQKV;
+    unsigned wq[REP], wk, wv;
+#pragma unroll
+    for (int r = 0; r < REP; ++r) wq[r] = ld4_sc1(row + (long)(kvh * REP + r) * HD + 2 * lane);
+    wk = ld4_sc1(row + (long)(QA_HEADS + kvh) * HD + 2 * lane);
+    wv = ld4_sc1(row + (long)(QA_HEADS + QA_KVH + kvh) * HD + 2 * lane);
+    const float rc = a.rope_cos[(long)b * HALF + lane], rs = a.rope_sin[(long)b * HALF + lane];
+    const float w1 = bf16_to_f32(a.qn_w[lane]), w2 = bf16_to_f32(a.qn_w[lane + HALF]);
+    const float kw1 = bf16_to_f32(a.kn_w[lane]), kw2 = bf16_to_f32(a.kn_w[lane + HALF]);
+    auto pick = [&](unsigned w, int src_lane) {
+        const unsigned v = (unsigned)__shfl((int)w, src_lane, 64);
+        return (bf16_t)((lane & 1) ? v >> 16 : v & 0xffffu);
+    };
+    float x1[REP], x2[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) { x1[r] = bf16_to_f32(pick(wq[r], lane >> 1)); x2[r] = bf16_to_f32(pick(wq[r], 32 + (lane >> 1))); }
+    const float kx1 = bf16_to_f32(pick(wk, lane >> 1)), kx2 = bf16_to_f32(pick(wk, 32 + (lane >> 1)));
+    const bf16_t vown[2] = {pick(wv, lane >> 1), pick(wv, 32 + (lane >> 1))};
+    float qa[REP][2];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        const float inv = rsqrtf(lane_sum<64>(x1[r] * x1[r] + x2[r] * x2[r]) / (float)HD + a.eps);
+        norm_rope_pair(x1[r], x2[r], w1, w2, inv, rc, rs, qa[r][0], qa[r][1]);
+        s_q[(wave * REP + r) * HD + lane] = f32_to_bf16(qa[r][0]);
+        s_q[(wave * REP + r) * HD + lane + HALF] = f32_to_bf16(qa[r][1]);
+    }
+    {
+        const float inv = rsqrtf(lane_sum<64>(kx1 * kx1 + kx2 * kx2) / (float)HD + a.eps);
+        float k1, k2;
+        norm_rope_pair(kx1, kx2, kw1, kw2, inv, rc, rs, k1, k2);
+        if (wave == WAVES - 1) {
+            bf16_t* dk = cache.k + cache.off(b, kvh, pos);
+            dk[lane] = f32_to_bf16(k1);
+            dk[lane + HALF] = f32_to_bf16(k2);
+        }
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            const float d = lane_sum<64>(qa[r][0] * k1 + qa[r][1] * k2);
+            if (wave == WAVES - 1 && lane == 0) s_new[r] = d * a.scale;
+        }
+        bf16_t* dvf = cache.vf + cache.off(b, kvh, 0);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = lane + 64 * ii;
+            s_vn[i] = bf16_to_f32(vown[ii]);                         // every wave writes the same value
+            if (wave == WAVES - 2) dvf[qa_vfrag_index<HD>(pos, i)] = vown[ii];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    mfma_bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (fr < REP) u = *reinterpret_cast<const uint4*>(&s_q[(wave * REP + fr) * HD + ks * 32 + g * 8]);
+        qf[ks] = __builtin_bit_cast(mfma_bf16x8, u);
+    }
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float scale = a.scale;
+    for (int c0 = wave; c0 < nchunks; c0 += WAVES * UNR) {
+        if (c0 != wave) issue(c0, nchunks);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int chunk = c0 + u * WAVES;
+            if (chunk < nchunks) {                                       // wave-uniform
+                f32x4 sc[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, kreg[u][h * KS + ks]), qf[ks], acc, 0, 0, 0);
+                    sc[h] = acc;
+                }
+                const int key0 = chunk * 32 + g * 4;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = key0 + h * 16 + j < pos ? sc[h][j] * scale : -INFINITY;
+                        sc[h][j] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __expf(m_run - m_new);
+                float rsum = 0.0f;
+                unsigned pk[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const unsigned pw = pack_bf16x2(__expf(sc[h][j] - m_new), __expf(sc[h][j + 1] - m_new));
+                        rsum += bf16_lo(pw) + bf16_hi(pw);
+                        pk[h * 2 + j / 2] = pw;
+                    }
+                l_run = l_run * alpha + rsum;
+                m_run = m_new;
+                const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), 0));
+                const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), 1));
+                uint4 vv[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) vv[dt] = vreg[u][dt];
+                if (chunk * 32 + 32 > pos) {
+                    unsigned msk[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int k_lo = key0 + (w >> 1) * 16 + (w & 1) * 2;
+                        msk[w] = (k_lo < pos ? 0x0000ffffu : 0u) | (k_lo + 1 < pos ? 0xffff0000u : 0u);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) { vv[dt].x &= msk[0]; vv[dt].y &= msk[1]; vv[dt].z &= msk[2]; vv[dt].w &= msk[3]; }
+                }
+                const mfma_bf16x8 pa = __builtin_bit_cast(mfma_bf16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    o[dt][0] *= a0;
+                    o[dt][1] *= a1;
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, __builtin_bit_cast(mfma_bf16x8, vv[dt]), o[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (lane < REP) { s_m[wave * REP + lane] = m_run; s_l[wave * REP + lane] = l_run; }
+    if (g == 0) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            s_o[(wave * REP + 0) * HD + dt * 16 + fr] = o[dt][0];
+            s_o[(wave * REP + 1) * HD + dt * 16 + fr] = o[dt][1];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < REP * HD; i += WAVES * 64) {
+        const int r = i / HD, d = i - r * HD;
+        float mm = s_new[r];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) mm = fmaxf(mm, s_m[w * REP + r]);
+        const float pn = __expf(s_new[r] - mm);
+        float num = pn * s_vn[d], den = pn;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const float mw = s_m[w * REP + r];
+            if (mw != -INFINITY) {
+                const float al = __expf(mw - mm);
+                num += s_o[(w * REP + r) * HD + d] * al;
+                den += s_l[w * REP + r] * al;
+            }
+        }
+        a.out[(long)b * QA_HEADS * HD + (long)(kvh * REP + r) * HD + d] = f32_to_bf16(num / den);
+    }
+}
+
+}  // namespace
+
+bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_ctx) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    static std::mutex mu;
+    static int cus[64] = {0};
+    QASR_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev >= 0 && dev < 64 && !cus[dev]) { QASR_HIP(hipGetDeviceProperties(&p, dev)); cus[dev] = p.multiProcessorCount; }
+    }
+    return H == CH_H && heads == QA_HEADS && kv_heads == QA_KVH && hd == QA_HD && B >= 1 && B <= 32 && max_ctx % 32 == 0 && dev < 64 &&
+           cus[dev] >= 256;
+}
+
+void decode_qa_launch(const DecQaArgs& a, hipStream_t s) {
+    if (a.B < 1 || a.B > 32) throw std::invalid_argument("decode qa: 1..32 batch rows");
+    if (!a.cache.vf || a.cache.max_ctx % 32) throw std::invalid_argument("decode qa: fragment-major V image / capacity");
+    if (a.B <= 16) {
+        auto k = decode_qa_kernel<1>;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k), L_TOTAL);
+        hipLaunchKernelGGL(k, dim3(256), dim3(CT), L_TOTAL, s, a);
+    } else {
+        auto k = decode_qa_kernel<2>;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(k), L_TOTAL);
+        hipLaunchKernelGGL(k, dim3(256), dim3(CT), L_TOTAL, s, a);
+    }
+}
+
+}  // namespace qasr

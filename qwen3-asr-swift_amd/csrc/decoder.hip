@@ -569,7 +569,9 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     // chain > 0: a layer's linears run as one persistent launch (dec_chain.hip) wherever it has an instantiation: the float 0.6B geometry,
     // the whole batch in one row group (the arrival counters belong to one step of one engine), up to 32 rows
     const int chain = (!decw_.quant && r0 == 0 && !stamp_buf_ && decode_chain_supported(H, nq, I, nh * hd, nr)) ? tuning().chain : 0;
-    if (chain) decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
+    const bool qa = !decw_.quant && r0 == 0 && !stamp_buf_ && chain < 3 && tuning().qa &&
+                    decode_qa_supported(H, cfg_.heads, cfg_.kv_heads, hd, nr, max_ctx_) && nh * hd == 4096;
+    if (chain || qa) decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
         KVLayout kv{kcache_[l]->as<bf16_t>(), nullptr, max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
@@ -579,20 +581,27 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         unsigned long long* dbg = (stamp_buf_ && l == stamp_layer_) ? stamp_buf_ : nullptr;
         const size_t dbg_stride = (size_t)512 * 16 * 8;
         DecGemvArgs a{};
+        a.B = nr;
         auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) { decode_gemv(epi, a, qi, norm_w, h, s); };
-        if (chain < 3 || l == 0) {         // chain 3: layer l's q|k|v came out of layer l - 1's launch
-            a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
-            decode_gemv_set_debug(dbg);
-            gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
-        }
         const RopeRows rr = rope_rows(r0);
-        decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
-                                rr.cos_rows, rr.sin_rows, kv, at, s, dbg ? dbg + 4 * dbg_stride : nullptr);
+        if (qa) {
+            DecQaArgs q{x, L.ln1, L.wqkv_p, qkv, gs.ctx_len, L.qn, L.kn, rr.cos_rows, rr.sin_rows, kv, at, nr, cfg_.rms_eps,
+                        1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_};
+            decode_qa_launch(q, s);
+        } else {
+            if (chain < 3 || l == 0) {         // chain 3: layer l's q|k|v came out of layer l - 1's launch
+                a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = x; a.B = nr; a.N = nh * hd; a.K = H; a.out = qkv;
+                decode_gemv_set_debug(dbg);
+                gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
+            }
+            decode_attention_launch(qkv, gs.ctx_len, nr, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
+                                    rr.cos_rows, rr.sin_rows, kv, at, s, dbg ? dbg + 4 * dbg_stride : nullptr);
+        }
         if (chain) {
             const bool last = l + 1 == cfg_.dec_layers;
             const DecLayerW& Ln = decw_.layers[last ? l : l + 1];
             DecChainArgs c{at, L.wo_p, x, L.ln2, L.wgu_p, act, L.wdown_p, Ln.ln1, Ln.wqkv_p, qkv, nr, cfg_.rms_eps,
-                           d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_};
+                           d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_, (chain_dbg_ && l == cfg_.dec_layers / 2) ? chain_dbg_ : nullptr};
             int phases = CHAIN_O | CHAIN_GU;
             if (chain >= 2) phases |= CHAIN_DOWN;
             if (chain >= 3 && !last) phases |= CHAIN_QKV;
@@ -1065,6 +1074,36 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                     acc[1] / cnt / 100, acc[2] / cnt / 100, acc[3] / cnt / 100, acc[4] / cnt / 100, acc[5] / cnt / 100, acc[6] / cnt / 100, acc[7] / cnt / 100);
         }
         fprintf(stderr, "[qasr] prompt attention stamps: span %.2f us\n", (double)(t1 - t0) / 100);
+    }
+    if (which == 6) {
+        // diagnostic: one real (eager) decode step with the middle layer's persistent launch stamped (dec_chain.hip, ST instantiation)
+        if (!tuning().chain) throw std::invalid_argument("kernel_probe 6: set the chain knob first");
+        DevBuf d;
+        const size_t n = (size_t)256 * 32;
+        d.alloc(n * sizeof(unsigned long long));
+        std::vector<unsigned long long> hst(n);
+        static const char* names[19] = {"entry", "O staged", "O summed", "O signalled", "GU wait over", "GU rows in", "GU staged", "GU summed",
+                                        "GU signalled", "DOWN wait over", "DOWN rows in", "DOWN staged", "DOWN summed", "DOWN signalled",
+                                        "QKV wait over", "QKV rows in", "QKV staged", "QKV summed", "QKV stored"};
+        for (int rep = 0; rep < 3; ++rep) {
+            QASR_HIP(hipMemsetAsync(d.p, 0, d.bytes, s));
+            chain_dbg_ = d.as<unsigned long long>();
+            run_decode_step(false, false, 0, rows, s, true);
+            chain_dbg_ = nullptr;
+            QASR_HIP(hipMemcpyAsync(hst.data(), d.p, d.bytes, hipMemcpyDeviceToHost, s));
+            QASR_HIP(hipStreamSynchronize(s));
+            if (rep < 2) continue;
+            unsigned long long t0 = ~0ull;
+            for (size_t w = 0; w < 256; ++w) if (hst[w * 32]) t0 = std::min(t0, hst[w * 32]);
+            for (int q = 0; q < 19; ++q) {
+                double sum = 0, lo = 1e30, hi = 0; int cnt = 0;
+                for (size_t w = 0; w < 256; ++w) if (hst[w * 32 + q]) { const double v = (double)(hst[w * 32 + q] - t0) / 100; sum += v; lo = std::min(lo, v); hi = std::max(hi, v); ++cnt; }
+                if (cnt) fprintf(stderr, "[qasr] chain stamps %-16s workgroups %3d  min %6.2f  mean %6.2f  max %6.2f us\n", names[q], cnt, lo, sum / cnt, hi);
+            }
+        }
+        *avg_ms = 0.f;
+        *bytes_per_launch = 0;
+        return;
     }
     if (which == 0 && tuning().stamps_insitu) {
         // one real decode step (eager, all layers, cold weights) with layer 14's five launches stamped

@@ -16,6 +16,7 @@ struct Tuning {
     int gemv_wide = 1;       // K = 6144 (1.7B down-projection): 1 two-phase LDS image, weights in registers (dec_gemv_wide.hip) | 0 generic kernel
     int chain = 0;           // decode layer's linears as one persistent launch with in-launch hand-offs (dec_chain.hip): 0 five launches per layer |
                              // 1 o-proj -> gate|up | 2 ... -> down | 3 ... -> the next layer's q|k|v (two launches per layer: attention + chain)
+    int qa = 0;              // q|k|v projection + decode attention of a layer as one launch, K / V requested before the projection (dec_qa.hip): 1 | 0 two launches
     int chain_nt = 0;        // chain weight stream: 1 non-temporal loads | 0 default cache policy
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
     int da_spec = 3;         // K/V requests issued before ctx_len is known: 0 none | 1 each wave's first chunk (no byte past the context at 256+ keys) |

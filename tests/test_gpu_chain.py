@@ -24,6 +24,7 @@ def eng():
     yield e
     e.set_tuning("chain", 0)
     e.set_tuning("chain_nt", 0)
+    e.set_tuning("qa", 0)
     e.close()
 
 
@@ -41,14 +42,16 @@ def test_chain_equals_five_launch_layer_bit_for_bit(eng, nt):
     eng.set_tuning("chain_nt", nt)
     base = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
     assert len({tuple(t) for t in base[2][-1]}) > 1            # the rows do differ
-    for mode in (1, 2, 3):
+    for mode, qa in ((1, 0), (2, 0), (3, 0), (0, 1), (2, 1)):
         eng.set_tuning("chain", mode)
+        eng.set_tuning("qa", qa)
         got = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
-        assert np.array_equal(got[0], base[0]), mode
-        assert np.array_equal(got[1], base[1]), (mode, float(np.abs(got[1] - base[1]).max()))
+        assert np.array_equal(got[0], base[0]), (mode, qa)
+        assert np.array_equal(got[1], base[1]), (mode, qa, float(np.abs(got[1] - base[1]).max()))
         for b, (g, w) in zip((1, 8, 16, 17, 32), zip(got[2], base[2])):
-            assert g == w, (mode, b)
+            assert g == w, (mode, qa, b)
     eng.set_tuning("chain", 0)
+    eng.set_tuning("qa", 0)
 
 
 def test_chain_natural_eos_and_reruns(eng):
@@ -57,7 +60,29 @@ def test_chain_natural_eos_and_reruns(eng):
     clips = [synth.synth_waveform(40 + k, 0.8 + 0.1 * (k % 7)) for k in range(24)]
     eng.set_tuning("chain", 0)
     want = eng.transcribe_batch(clips, max_tokens=16)
-    eng.set_tuning("chain", 3)
-    for _ in range(3):
-        assert eng.transcribe_batch(clips, max_tokens=16) == want
+    for mode, qa in ((3, 0), (2, 1)):
+        eng.set_tuning("chain", mode)
+        eng.set_tuning("qa", qa)
+        for _ in range(3):
+            assert eng.transcribe_batch(clips, max_tokens=16) == want
     eng.set_tuning("chain", 0)
+    eng.set_tuning("qa", 0)
+
+
+def test_qa_long_context_second_round():
+    """q|k|v + attention in one launch (csrc/dec_qa.hip): a context beyond the 512 keys that the first round of requests covers (16 chunks
+    of 32 keys over 8 waves) takes further rounds inside the sweep, wave 0 requests its chunks only after the hand-off: a 41 s clip
+    (16 + 533 prompt positions) next to a short one, bit-equal to the two-launch layer."""
+    t = dataclasses.replace(C.TEXT_SMALL, layers=2)
+    sd = synth.synth_state_dict(dataclasses.replace(C.AUDIO_SMALL, layers=1), t, seed=2, init="stress")
+    e = gpu_util.Engine("0.6B", max_batch=2, max_audio_seconds=42, max_new_tokens=24, enc_layers=1, dec_layers=2)
+    try:
+        e.load_state_dict(sd)
+        clips = [synth.synth_waveform(3, 41.0), synth.synth_waveform(4, 2.0)]
+        e.set_tuning("qa", 0)
+        want = e.transcribe_batch(clips, max_tokens=20, ignore_eos=True)
+        e.set_tuning("qa", 1)
+        assert e.transcribe_batch(clips, max_tokens=20, ignore_eos=True) == want
+    finally:
+        e.set_tuning("qa", 0)
+        e.close()
