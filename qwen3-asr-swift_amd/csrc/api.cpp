@@ -180,7 +180,7 @@ int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps) {
     QASR_GUARD(e, e->impl->batch_timings(ms, n_steps));
 }
 int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch) {
-    if (!e || !avg_ms || !bytes_per_launch || reps <= 0 || which < 0 || which > 6) return QASR_ERR_INVALID;
+    if (!e || !avg_ms || !bytes_per_launch || reps <= 0 || which < 0 || which > 7) return QASR_ERR_INVALID;
     QASR_GUARD(e, e->impl->kernel_probe(which, reps, avg_ms, bytes_per_launch));
 }
 

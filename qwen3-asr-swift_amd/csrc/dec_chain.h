@@ -33,6 +33,7 @@ struct DecChainArgs {
     unsigned epoch;         // chain launches earlier in this step: the counters count up through a step
     int* err;               // device word; CHAIN_ERR_TIMEOUT is or-ed in when a wait gives up
     unsigned long long* dbg = nullptr;   // diagnostic: [256][32] phase stamps of this launch (qasr_kernel_probe 6), null in product launches
+    int proto = 0;          // arrival counters: 0 sharded (a producer adds to one of 8, a consumer polls all 8) | 1 replicated (adds to all, polls one)
 };
 
 // q|k|v projection + decode attention of one layer as one launch (dec_qa.hip): the K / V stream is requested before the projection runs
@@ -51,6 +52,7 @@ struct DecQaArgs {
     unsigned* ctr;          // the chain's counter block (block 3 is used here)
     unsigned epoch;         // layer index
     int* err;
+    unsigned long long* dbg = nullptr;   // diagnostic: [256][32] phase stamps (qasr_kernel_probe 7), null in product launches
 };
 bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_ctx);
 void decode_qa_launch(const DecQaArgs& a, hipStream_t s);

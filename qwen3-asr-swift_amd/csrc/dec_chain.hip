@@ -38,8 +38,14 @@ __device__ __forceinline__ uint2 resid_add(uint2 r, const f32x4& acc) {
 
 // ST: diagnostic instantiation (qasr_kernel_probe 6): thread 0 of every workgroup stamps the 100 MHz clock into a.dbg[wg * 32 + i]:
 //   0 entry | O: 1 staged 2 summed 3 signalled | GU: 4 wait over 5 rows in 6 staged 7 summed 8 signalled | DOWN: 9..13 | QKV: 14..18 (18 = stored)
-template <int PH, int NB, bool NTW, bool ST>
+// PF: weight requests staged -- a workgroup with an O unit asks for its later phases' tiles once the O sums are in, the others wait PF_TICKS
+// before their first request (all at once, the 31 MB of requests delay the first phase's activation rows: staged at 4.7 us instead of 1.1,
+// profiles/r04_stamps_chain.txt); !PF: everything at kernel entry.
+template <int PH, int NB, bool PF, bool ST>
 __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
+    constexpr bool NTW = false;
+    constexpr unsigned long long PF_TICKS = 250;                       // 2.5 us of the 100 MHz clock
+    const unsigned long long t_entry = PF ? wall_clock64() : 0ull;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
     const int srow = tid >> 5, scol = tid & 31;
@@ -77,16 +83,19 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
         uint4 wO[1][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) wO[0][i] = ld_weight<NTW>(a.wo_p + ((long)ot * (CH_NQ / 32) + wave + CWAVES * i) * 512 + lane * 8);
-        if constexpr (P_GU) {            // wg < 128 < 192: every O workgroup has a gate|up unit
+        auto later_tiles = [&]() {
+            if constexpr (P_GU) {            // wg < 128 < 192: every O workgroup has a gate|up unit
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wB[t][i] = ld_weight<NTW>(a.wgu_p + ((long)(2 * wg + t) * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
-        }
-        if constexpr (P_QKV) {
+                    for (int i = 0; i < 4; ++i) wB[t][i] = ld_weight<NTW>(a.wgu_p + ((long)(2 * wg + t) * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
+            }
+            if constexpr (P_QKV) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wC[0][i] = ld_weight<NTW>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
-        }
+                for (int i = 0; i < 4; ++i) wC[0][i] = ld_weight<NTW>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
+            }
+        };
+        if constexpr (!PF) later_tiles();
         if (r0 + srow >= B) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) xo[0][i] = make_uint4(0, 0, 0, 0);
@@ -95,10 +104,12 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
         chain_mma<1, 1, 8, false, ST>(wO, xo, nullptr, 0.f, s_x, s_red, acc, st + 1);
         if (wave == 0) {
             if (r0 + fr < B) st8_sc1(xout, resid_add(rsd, acc[0][0]));
-            seam_signal(a.ctr, 0, wg);
+            if (a.proto) seam_signal_r(a.ctr, 0); else seam_signal(a.ctr, 0, wg);
             CH_STAMP(3);
         }
+        if constexpr (PF) later_tiles();
     } else {
+        if constexpr (PF) { while (wall_clock64() - t_entry < PF_TICKS) __builtin_amdgcn_s_sleep(8); }
         if (has_down) {
             const int dt = (wg - DOWN0) & 63;
 #pragma unroll
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
 
     // ---- phase GU: act[rows][16 cols] = swiglu(rmsnorm(x) . Wg^T, rmsnorm(x) . Wu^T) -------------------------------------------------
     if (has_gu) {
-        if (!seam_wait(a.ctr, 0, (a.epoch + 1) * (8 * NB), a.err, s_flag)) return;
+        if (!(a.proto ? seam_wait_r(a.ctr, 0, (a.epoch + 1) * (64 * NB), a.err, s_flag) : seam_wait(a.ctr, 0, (a.epoch + 1) * (8 * NB), a.err, s_flag))) return;
         CH_STAMP(4);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, 32 * CH_H * 2, 0x00020000);
         uint4 xr[NB][4];
@@ -152,14 +163,14 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
                     st8_sc1(a.act + (long)row * CH_I + wg * 16 + fc * 4, pack_bf16x4(v));
                 }
             }
-            seam_signal(a.ctr, 1, wg);
+            if (a.proto) seam_signal_r(a.ctr, 1); else seam_signal(a.ctr, 1, wg);
             CH_STAMP(8);
         }
     }
 
     // ---- phase DOWN: x[rows][16 cols] += act[rows] . Wd[tile]^T --------------------------------------------------------------------
     if (has_down) {
-        if (!seam_wait(a.ctr, 1, (a.epoch + 1) * 24, a.err, s_flag)) return;
+        if (!(a.proto ? seam_wait_r(a.ctr, 1, (a.epoch + 1) * 192, a.err, s_flag) : seam_wait(a.ctr, 1, (a.epoch + 1) * 24, a.err, s_flag))) return;
         CH_STAMP(9);
         const int du = wg - DOWN0, dt = du & 63, r0 = (du >> 6) * 16;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.act, 0, 32 * CH_I * 2, 0x00020000);
@@ -181,14 +192,14 @@ __global__ __launch_bounds__(CT, 2) void decode_chain_kernel(DecChainArgs a) {
         chain_mma<1, 1, 12, false, ST>(wAD, xr, nullptr, 0.f, s_x, s_red, acc, st + 11);
         if (wave == 0) {
             if (r0 + fr < B) st8_sc1(xout, resid_add(rsd, acc[0][0]));
-            seam_signal(a.ctr, 2, du);
+            if (a.proto) seam_signal_r(a.ctr, 2); else seam_signal(a.ctr, 2, du);
             CH_STAMP(13);
         }
     }
 
     // ---- phase QKV: the next layer's q|k|v[rows][16 cols] = rmsnorm(x) . Wqkv[tile]^T (read by the next launch: plain stores) --------
     if constexpr (P_QKV) {
-        if (!seam_wait(a.ctr, 2, (a.epoch + 1) * (8 * NB), a.err, s_flag)) return;
+        if (!(a.proto ? seam_wait_r(a.ctr, 2, (a.epoch + 1) * (64 * NB), a.err, s_flag) : seam_wait(a.ctr, 2, (a.epoch + 1) * (8 * NB), a.err, s_flag))) return;
         CH_STAMP(14);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, 32 * CH_H * 2, 0x00020000);
         uint4 xr[NB][4];
@@ -237,25 +248,22 @@ int device_cus() {
     return p.multiProcessorCount;
 }
 
-template <int PH, int NB, bool NTW>
+template <int PH, int NB, bool PF>
 void chain_go(const DecChainArgs& a, hipStream_t s) {
-    if (a.dbg) {                       // diagnostic launch: default-policy weight loads only
-        auto kst = decode_chain_kernel<PH, NB, false, true>;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(kst), L_TOTAL);
-        hipLaunchKernelGGL(kst, dim3(CH_GRID), dim3(CT), L_TOTAL, s, a);
-        return;
-    }
-    auto kern = decode_chain_kernel<PH, NB, NTW, false>;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L_TOTAL);
-    hipLaunchKernelGGL(kern, dim3(CH_GRID), dim3(CT), L_TOTAL, s, a);
+    auto go = [&](auto kern) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), L_TOTAL);
+        hipLaunchKernelGGL(kern, dim3(CH_GRID), dim3(CT), L_TOTAL, s, a);
+    };
+    if (a.dbg) go(decode_chain_kernel<PH, NB, PF, true>);        // diagnostic launch
+    else go(decode_chain_kernel<PH, NB, PF, false>);
 }
 
-template <int NB, bool NTW>
+template <int NB, bool PF>
 void chain_ph(int phases, const DecChainArgs& a, hipStream_t s) {
     switch (phases) {
-        case CHAIN_O | CHAIN_GU: chain_go<CHAIN_O | CHAIN_GU, NB, NTW>(a, s); break;
-        case CHAIN_O | CHAIN_GU | CHAIN_DOWN: chain_go<CHAIN_O | CHAIN_GU | CHAIN_DOWN, NB, NTW>(a, s); break;
-        case CHAIN_O | CHAIN_GU | CHAIN_DOWN | CHAIN_QKV: chain_go<CHAIN_O | CHAIN_GU | CHAIN_DOWN | CHAIN_QKV, NB, NTW>(a, s); break;
+        case CHAIN_O | CHAIN_GU: chain_go<CHAIN_O | CHAIN_GU, NB, PF>(a, s); break;
+        case CHAIN_O | CHAIN_GU | CHAIN_DOWN: chain_go<CHAIN_O | CHAIN_GU | CHAIN_DOWN, NB, PF>(a, s); break;
+        case CHAIN_O | CHAIN_GU | CHAIN_DOWN | CHAIN_QKV: chain_go<CHAIN_O | CHAIN_GU | CHAIN_DOWN | CHAIN_QKV, NB, PF>(a, s); break;
         default: throw std::invalid_argument("decode chain: unsupported phase set");
     }
 }
@@ -268,9 +276,11 @@ bool decode_chain_supported(int H, int nq, int I, int nqkv, int B) {
 
 void decode_chain_launch(int phases, const DecChainArgs& a, hipStream_t s) {
     if (a.B < 1 || a.B > 32) throw std::invalid_argument("decode chain: 1..32 batch rows");
-    const bool ntw = tuning().chain_nt != 0;
-    if (a.B <= 16) { if (ntw) chain_ph<1, true>(phases, a, s); else chain_ph<1, false>(phases, a, s); }
-    else { if (ntw) chain_ph<2, true>(phases, a, s); else chain_ph<2, false>(phases, a, s); }
+    DecChainArgs b = a;
+    b.proto = tuning().chain_proto;
+    const bool pf = tuning().chain_pf != 0;
+    if (a.B <= 16) { if (pf) chain_ph<1, true>(phases, b, s); else chain_ph<1, false>(phases, b, s); }
+    else { if (pf) chain_ph<2, true>(phases, b, s); else chain_ph<2, false>(phases, b, s); }
 }
 
 void decode_chain_reset(unsigned* ctr, hipStream_t s) { QASR_HIP(hipMemsetAsync(ctr, 0, CHAIN_CTR_BYTES, s)); }

@@ -78,6 +78,16 @@ __device__ __forceinline__ bool seam_wait_n(const unsigned* c0, int nshards, uns
 __device__ __forceinline__ bool seam_wait(const unsigned* ctr, int seam, unsigned target, int* err, int* s_flag) {
     return seam_wait_n(ctr + seam * CHAIN_SHARDS * CHAIN_SHARD_WORDS, CHAIN_SHARDS, target, err, s_flag);
 }
+// Replicated form of a seam's counter (MI355X_MICROARCH.md, "Valid forms", second table row): every producer adds to ALL 8 replicas with one
+// wave instruction (8 active lanes, 8 lines), every consumer polls ONE replica -- 32 pollers per line instead of 256 pollers on each of 8 lines.
+__device__ __forceinline__ void seam_signal_r(unsigned* ctr, int seam) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x < CHAIN_SHARDS)
+        __hip_atomic_fetch_add(ctr + (seam * CHAIN_SHARDS + threadIdx.x) * CHAIN_SHARD_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool seam_wait_r(const unsigned* ctr, int seam, unsigned target, int* err, int* s_flag) {
+    return seam_wait_n(ctr + (seam * CHAIN_SHARDS + (blockIdx.x & (CHAIN_SHARDS - 1))) * CHAIN_SHARD_WORDS, 1, target, err, s_flag);
+}
 __device__ __forceinline__ unsigned ld4_sc1(const bf16_t* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

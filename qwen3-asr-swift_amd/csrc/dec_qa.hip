@@ -32,7 +32,9 @@ __device__ __forceinline__ long qa_vfrag_index(int key, int d) {       // = vfra
     return (((long)kb * DT + (d >> 4)) * 64 + (d & 15) + 16 * g) * 8 + half * 4 + j;
 }
 
-template <int NB>
+// ST: diagnostic instantiation (qasr_kernel_probe 7), stamps of the 100 MHz clock in a.dbg[wg * 32 + i]: thread 0: 0 entry, 1 rows staged,
+// 2 projection summed, 3 signalled, 4 wait over, 7 output stored; thread 64 (wave 1): 5 own rows AND its K / V chunks in, 6 sweep done
+template <int NB, bool ST>
 __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     constexpr int HD = QA_HD, REP = 2, KS = HD / 32, DT = HD / 16, HALF = HD / 2, WAVES = CWAVES, UNR = QA_UNR;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -47,6 +49,9 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     float* s_red = reinterpret_cast<float*>(dsm + L_RED);
     int* s_flag = reinterpret_cast<int*>(dsm + L_FLAG);
     const KVLayout cache = a.cache;
+    unsigned long long* st = ST ? a.dbg + (long)wg * 32 : nullptr;
+#define QA_STAMP(i, t) do { if constexpr (ST) { if (tid == (t)) st[i] = wall_clock64(); } } while (0)
+    QA_STAMP(0, 0);
 
     // ---- requests, oldest first: context length, norm weights, activation rows, weight tile, then the K / V chunks ------------------
     int pos = a.ctx_len[bq];
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
                 for (int dt = 0; dt < DT; ++dt)
                     vreg[u][dt] = *reinterpret_cast<const uint4*>(dummy ? kdummy : vfb + ((long)ch_early[u] * DT + dt) * 512);
         };
-        chain_mma<1, NB, 4, true>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, nullptr, issue_v);
+        chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1, issue_v);
         if (wave == 0) {
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
@@ -119,10 +124,12 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             // tile -> kv head it feeds: q columns (tiles 0..127, 16 per kv head), then k (8 per head), then v
             const int grp = wg < 128 ? wg >> 4 : (wg < 192 ? (wg - 128) >> 3 : (wg - 192) >> 3);
             seam_signal(a.ctr, 3, grp);
+            QA_STAMP(3, 0);
         }
     }
     if (!has_att) return;
     if (!seam_wait_n(a.ctr + (3 * CHAIN_SHARDS + kvh) * CHAIN_SHARD_WORDS, 1, (a.epoch + 1) * 32, a.err, s_flag)) return;
+    QA_STAMP(4, 0);
 
     // ---- attention unit (b, kvh): decode_attention_mfma_kernel's body with the first round of K / V already requested -----------------
     auto issue = [&](int chunk0, int limit) {
@@ -164,6 +171,8 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         const unsigned v = (unsigned)__shfl((int)w, src_lane, 64);
         return (bf16_t)((lane & 1) ? v >> 16 : v & 0xffffu);
     };
+    if constexpr (ST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    QA_STAMP(5, 64);
     float x1[REP], x2[REP];
 #pragma unroll
     for (int r = 0; r < REP; ++r) { x1[r] = bf16_to_f32(pick(wq[r], lane >> 1)); x2[r] = bf16_to_f32(pick(wq[r], 32 + (lane >> 1))); }
@@ -279,6 +288,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             }
         }
     }
+    QA_STAMP(6, 64);
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (lane < REP) { s_m[wave * REP + lane] = m_run; s_l[wave * REP + lane] = l_run; }
@@ -308,6 +318,8 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         }
         a.out[(long)b * QA_HEADS * HD + (long)(kvh * REP + r) * HD + d] = f32_to_bf16(num / den);
     }
+    QA_STAMP(7, 0);
+#undef QA_STAMP
 }
 
 }  // namespace
@@ -329,15 +341,12 @@ bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_
 void decode_qa_launch(const DecQaArgs& a, hipStream_t s) {
     if (a.B < 1 || a.B > 32) throw std::invalid_argument("decode qa: 1..32 batch rows");
     if (!a.cache.vf || a.cache.max_ctx % 32) throw std::invalid_argument("decode qa: fragment-major V image / capacity");
-    if (a.B <= 16) {
-        auto k = decode_qa_kernel<1>;
+    auto go = [&](auto k) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k), L_TOTAL);
         hipLaunchKernelGGL(k, dim3(256), dim3(CT), L_TOTAL, s, a);
-    } else {
-        auto k = decode_qa_kernel<2>;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(k), L_TOTAL);
-        hipLaunchKernelGGL(k, dim3(256), dim3(CT), L_TOTAL, s, a);
-    }
+    };
+    if (a.dbg) { if (a.B <= 16) go(decode_qa_kernel<1, true>); else go(decode_qa_kernel<2, true>); }
+    else { if (a.B <= 16) go(decode_qa_kernel<1, false>); else go(decode_qa_kernel<2, false>); }
 }
 
 }  // namespace qasr

@@ -586,7 +586,8 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
         const RopeRows rr = rope_rows(r0);
         if (qa) {
             DecQaArgs q{x, L.ln1, L.wqkv_p, qkv, gs.ctx_len, L.qn, L.kn, rr.cos_rows, rr.sin_rows, kv, at, nr, cfg_.rms_eps,
-                        1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_};
+                        1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_,
+                        (qa_dbg_ && l == cfg_.dec_layers / 2) ? qa_dbg_ : nullptr};
             decode_qa_launch(q, s);
         } else {
             if (chain < 3 || l == 0) {         // chain 3: layer l's q|k|v came out of layer l - 1's launch
@@ -1075,21 +1076,25 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         }
         fprintf(stderr, "[qasr] prompt attention stamps: span %.2f us\n", (double)(t1 - t0) / 100);
     }
-    if (which == 6) {
-        // diagnostic: one real (eager) decode step with the middle layer's persistent launch stamped (dec_chain.hip, ST instantiation)
-        if (!tuning().chain) throw std::invalid_argument("kernel_probe 6: set the chain knob first");
+    if (which == 6 || which == 7) {
+        // diagnostic: one real (eager) decode step with the middle layer's persistent launch stamped (dec_chain.hip / dec_qa.hip, ST instantiations)
+        if (which == 6 && !tuning().chain) throw std::invalid_argument("kernel_probe 6: set the chain knob first");
+        if (which == 7 && !tuning().qa) throw std::invalid_argument("kernel_probe 7: set the qa knob first");
         DevBuf d;
         const size_t n = (size_t)256 * 32;
         d.alloc(n * sizeof(unsigned long long));
         std::vector<unsigned long long> hst(n);
-        static const char* names[19] = {"entry", "O staged", "O summed", "O signalled", "GU wait over", "GU rows in", "GU staged", "GU summed",
+        static const char* qnames[19] = {"entry", "rows staged", "proj summed", "signalled", "wait over", "w1 rows+K/V in", "w1 sweep done", "stored",
+                                         "", "", "", "", "", "", "", "", "", "", ""};
+        static const char* cnames[19] = {"entry", "O staged", "O summed", "O signalled", "GU wait over", "GU rows in", "GU staged", "GU summed",
                                         "GU signalled", "DOWN wait over", "DOWN rows in", "DOWN staged", "DOWN summed", "DOWN signalled",
                                         "QKV wait over", "QKV rows in", "QKV staged", "QKV summed", "QKV stored"};
         for (int rep = 0; rep < 3; ++rep) {
             QASR_HIP(hipMemsetAsync(d.p, 0, d.bytes, s));
-            chain_dbg_ = d.as<unsigned long long>();
+            (which == 6 ? chain_dbg_ : qa_dbg_) = d.as<unsigned long long>();
             run_decode_step(false, false, 0, rows, s, true);
             chain_dbg_ = nullptr;
+            qa_dbg_ = nullptr;
             QASR_HIP(hipMemcpyAsync(hst.data(), d.p, d.bytes, hipMemcpyDeviceToHost, s));
             QASR_HIP(hipStreamSynchronize(s));
             if (rep < 2) continue;
@@ -1098,6 +1103,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             for (int q = 0; q < 19; ++q) {
                 double sum = 0, lo = 1e30, hi = 0; int cnt = 0;
                 for (size_t w = 0; w < 256; ++w) if (hst[w * 32 + q]) { const double v = (double)(hst[w * 32 + q] - t0) / 100; sum += v; lo = std::min(lo, v); hi = std::max(hi, v); ++cnt; }
+                const char* const* names = which == 6 ? cnames : qnames;
                 if (cnt) fprintf(stderr, "[qasr] chain stamps %-16s workgroups %3d  min %6.2f  mean %6.2f  max %6.2f us\n", names[q], cnt, lo, sum / cnt, hi);
             }
         }

@@ -255,6 +255,7 @@ private:
     DevBuf d_vt_;
     DevBuf d_px_, d_ph_, d_pqkv_, d_pqr_, d_pattn_, d_pact_;   // prefill (packed prompt positions)
     DevBuf d_dx_, d_dh_, d_dqkv_, d_dattn_, d_dact_, d_logits_, d_part_val_, d_part_idx_;   // decode rows
+    unsigned long long* qa_dbg_ = nullptr;
     unsigned long long* chain_dbg_ = nullptr;                  // diagnostic stamps of the middle layer's chain launch (kernel_probe 6)
     DevBuf d_chain_ctr_;                                       // arrival counters of the persistent layer launch (dec_chain.h)
     HostBuf h_pmeta_;

@@ -17,7 +17,8 @@ struct Tuning {
     int chain = 0;           // decode layer's linears as one persistent launch with in-launch hand-offs (dec_chain.hip): 0 five launches per layer |
                              // 1 o-proj -> gate|up | 2 ... -> down | 3 ... -> the next layer's q|k|v (two launches per layer: attention + chain)
     int qa = 0;              // q|k|v projection + decode attention of a layer as one launch, K / V requested before the projection (dec_qa.hip): 1 | 0 two launches
-    int chain_nt = 0;        // chain weight stream: 1 non-temporal loads | 0 default cache policy
+    int chain_proto = 0;     // chain arrival counters: 0 sharded (add to one of 8, poll all 8) | 1 replicated (add to all 8, poll one)
+    int chain_pf = 0;        // chain weight requests: 0 every phase's tiles at kernel entry | 1 staged (first phase first)
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
     int da_spec = 3;         // K/V requests issued before ctx_len is known: 0 none | 1 each wave's first chunk (no byte past the context at 256+ keys) |
                              // 2 every chunk of the first round (1.26 x the algorithmic bytes at 32 x 30 s) | 3 = 2 up to 8 batch rows, 1 above

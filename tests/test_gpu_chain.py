@@ -23,7 +23,8 @@ def eng():
     e.load_state_dict(sd)
     yield e
     e.set_tuning("chain", 0)
-    e.set_tuning("chain_nt", 0)
+    e.set_tuning("chain_proto", 0)
+    e.set_tuning("chain_pf", 0)
     e.set_tuning("qa", 0)
     e.close()
 
@@ -34,12 +35,13 @@ def _run(eng, clips, emb, forced):
     return first, steps, [eng.transcribe_batch(clips[:b], max_tokens=7, ignore_eos=True) for b in (1, 8, 16, 17, 32)]
 
 
-@pytest.mark.parametrize("nt", [0, 1], ids=["default-policy", "nt-weights"])
-def test_chain_equals_five_launch_layer_bit_for_bit(eng, nt):
+@pytest.mark.parametrize("proto,pf", [(0, 0), (1, 1)], ids=["sharded-counters-all-requests-at-entry", "replicated-counters-staged-requests"])
+def test_chain_equals_five_launch_layer_bit_for_bit(eng, proto, pf):
     emb = P.bf16_round(torch.randn(33, 1024, generator=torch.Generator().manual_seed(7)) * 0.5).numpy()
     clips = [synth.synth_waveform(k, 1.0 + 0.17 * (k % 5)) for k in range(32)]
     eng.set_tuning("chain", 0)
-    eng.set_tuning("chain_nt", nt)
+    eng.set_tuning("chain_proto", proto)
+    eng.set_tuning("chain_pf", pf)
     base = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
     assert len({tuple(t) for t in base[2][-1]}) > 1            # the rows do differ
     for mode, qa in ((1, 0), (2, 0), (3, 0), (0, 1), (2, 1)):
