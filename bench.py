@@ -160,6 +160,7 @@ def kernel_source_stamp(files=("dec_attention.hip", "dec_rope.h", "dec_kernels.h
 
 
 GEMV_SOURCES = ("dec_gemv.hip", "dec_epilogue.h", "dec_kernels.h", "common.h")
+QA_SOURCES = ("dec_qa.hip", "dec_chain_dev.h", "dec_chain.h", "dec_rope.h", "dec_epilogue.h", "dec_kernels.h", "common.h")
 
 # Omnilingual-ASR-CTC (BASELINE configs[3]): FLOPs per clip as scratch/bench_ctc.py counts them -- conv stack 2 C k C_in per output frame
 # of each layer, projection, positional conv, per layer 2 (4 D^2 + 2 D F) + 4 T D attention, head 2 D V per encoder frame
@@ -312,6 +313,9 @@ def main():
     # the same passes with the batch already resident in HBM (no staging copy / H2D / planning in the timed region)
     dt_res = run_leg(model, clips, n_dec, args.steps, 1, world, gathered, inclusive=False)
     probe = {name: model.kernel_probe(which, 20) for which, name in ((0, "layer_gemv"), (1, "decode_attn"), (2, "lm_head"))}
+    # how the step of this batch is launched: with fused_qa a layer's q|k|v projection and attention are ONE launch (csrc/dec_qa.hip), which
+    # probe 1 then times (K / V rows + the q|k|v weights), and probe 0 is the three linears left
+    fused_qa, chain_mode, launches_per_layer = model.decode_structure()
 
     extras = {}
     if world == 1 and not args.no_extras:
@@ -332,13 +336,13 @@ def main():
         dom_ms, dom_bytes = probe["decode_attn"]
         traffic, traffic_note = None, None
         import glob
-        stamp = kernel_source_stamp()
+        stamp = kernel_source_stamp(QA_SOURCES) if fused_qa else kernel_source_stamp()
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             pmc = json.load(open(f))
-            if pmc.get("kernel_source_stamp") != stamp:
+            if pmc.get("qa_source_stamp" if fused_qa else "kernel_source_stamp") != stamp:
                 continue                   # measured on other kernel sources: stale, not quoted
-            traffic = pmc.get("decode_attention_bytes")
-            alg = pmc.get("decode_attention_algorithmic_bytes_at_that_context")
+            traffic = pmc.get("decode_qa_bytes" if fused_qa else "decode_attention_bytes")
+            alg = pmc.get("decode_qa_algorithmic_bytes_at_that_context" if fused_qa else "decode_attention_algorithmic_bytes_at_that_context")
             traffic_note = (f"profiles/{os.path.basename(f)} (kernel sources {stamp}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
                             f"separate --pmc passes of a 16-token run; algorithmic bytes at that run's mean context: {alg}")
             break
@@ -351,8 +355,10 @@ def main():
             if pmc.get("gemv_source_stamp") != gstamp or not pmc.get("layer_gemv_group_bytes"):
                 continue
             gemv_traffic = pmc["layer_gemv_group_bytes"]
-            gemv_traffic_note = (f"profiles/{os.path.basename(f)} (kernel sources {gstamp}): (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the four "
-                                 f"launches of a layer, separate --pmc passes of a 16-token run")
+            if bool(pmc.get("fused_qa")) != bool(fused_qa):
+                continue                   # the group had another number of launches in that run
+            gemv_traffic_note = (f"profiles/{os.path.basename(f)} (kernel sources {gstamp}): (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the "
+                                 f"{'three' if fused_qa else 'four'} launches of a layer, separate --pmc passes of a 16-token run")
             break
         if gemv_traffic is None:
             gemv_traffic_note = f"no PMC file under profiles/ matches the current GEMV kernel sources ({gstamp}); not quoted"
@@ -364,11 +370,12 @@ def main():
         gemv_ms, gemv_bytes = probe["layer_gemv"]
         share_attn = n_layers * steps_done * dom_ms / res_ms
         share_gemv = n_layers * steps_done * gemv_ms / res_ms
-        gemv_family = {"kernel": "decode_gemv2_kernel x4 per layer (q|k|v + o-proj + gate|up + down: one decoder layer's weights, streamed "
-                                 "once per step for all batch rows)",
+        n_gemv = 3 if fused_qa else 4
+        gemv_family = {"kernel": (f"decode_gemv2_kernel x{n_gemv} per layer (" + ("" if fused_qa else "q|k|v + ") + "o-proj + gate|up + down, streamed once per "
+                                  "step for all batch rows" + ("; the q|k|v projection runs inside the attention's launch" if fused_qa else "") + ")"),
                        "achieved": round(gemv_bytes / gemv_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(gemv_bytes / gemv_ms / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_layer": gemv_bytes,
-                       "avg_ms_per_layer": round(gemv_ms, 5), "avg_ms_per_launch": round(gemv_ms / 4, 5),
+                       "avg_ms_per_layer": round(gemv_ms, 5), "avg_ms_per_launch": round(gemv_ms / n_gemv, 5),
                        "share_of_gpu_time": round(share_gemv, 3)}
         wname = "bf16" if args.bits == 16 else f"MLX {args.bits}-bit decoder (packed in HBM), bf16 activations"
         out = {
@@ -398,26 +405,41 @@ def main():
             "stage_roofline": stage_roofline(B, args.seconds, n_dec, stage_ms, steps_done, args.bits),
         }
         attn_obj = {"bound": "hbm",
-                    "kernel": "decode_attention_mfma_kernel (one launch = one decoder layer's attention for all batch rows: "
-                              "K and V rows of every row's context are streamed once)",
+                    "kernel": ("decode_qa_kernel (one launch = one decoder layer's q|k|v projection AND attention for all batch rows: the K and V "
+                               "rows of every row's context and the 8.39 MB of q|k|v weights are streamed once; the stream is requested while the "
+                               "projection runs)" if fused_qa else
+                               "decode_attention_mfma_kernel (one launch = one decoder layer's attention for all batch rows: "
+                               "K and V rows of every row's context are streamed once)"),
                     "achieved": round(dom_bytes / dom_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(dom_bytes / dom_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": traffic_note,
                     "bytes_per_launch": dom_bytes, "avg_ms_per_launch": round(dom_ms, 5),
                     "share_of_gpu_time": round(share_attn, 3),
-                    "how": "algorithmic bytes = sum_b 2 (K,V) x 8 kv heads x 128 x 2 B x ctx_b at the probe's context; duration = HIP "
-                           "events on the engine stream around each of 20 launches, each preceded by an untimed weight-streaming "
-                           "launch as in the real step (qasr_kernel_probe)"}
+                    "how": ("algorithmic bytes = sum_b 2 (K,V) x 8 kv heads x 128 x 2 B x ctx_b at the probe's context + 4096 x 1024 x 2 B of q|k|v "
+                            "weights; duration = HIP events on the engine stream around each of 20 launches walking the 28 layers, so weights and "
+                            "K / V come from HBM as in the step (qasr_kernel_probe)" if fused_qa else
+                            "algorithmic bytes = sum_b 2 (K,V) x 8 kv heads x 128 x 2 B x ctx_b at the probe's context; duration = HIP "
+                            "events on the engine stream around each of 20 launches, each preceded by an untimed weight-streaming "
+                            "launch as in the real step (qasr_kernel_probe)")}
         other = {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)} for k, v in probe.items()}
         if share_gemv > share_attn:
             # the GEMV kernel takes more of the pass than the attention: IT is the dominant kernel and the object's headline figure;
             # the attention (closer to its roofline) is kept beside it, never instead of it
             out["roofline"] = {"bound": "hbm", **gemv_family, "traffic": gemv_traffic, "traffic_source": gemv_traffic_note,
-                               "how": "algorithmic bytes = the bf16 weights of one decoder layer (8.39 + 4.19 + 12.58 + 6.29 MB); duration = HIP events "
-                                      "on the engine stream around 20 x 4 launches walking the 28 layers (weights from HBM, as in the step)",
+                               "how": "algorithmic bytes = the bf16 weights the group streams (q|k|v 8.39, o-proj 4.19, gate|up 12.58, down 6.29 MB: those of its "
+                                      "launches); duration = HIP events on the engine stream around 20 groups walking the 28 layers (weights from HBM, as in the step)",
                                "attention": attn_obj, "other": other}
         else:
-            out["roofline"] = {**attn_obj, "family": gemv_family, "other": other}
+            out["roofline"] = {**attn_obj, "family": {**gemv_family, "traffic": gemv_traffic, "traffic_source": gemv_traffic_note}, "other": other}
+        # the whole pass against its roofline (MFMA part at the dense bf16 peak + decode bytes at the HBM peak), and the strictly
+        # serial inclusive figure beside the pipelined headline -- inside the object the driver keeps
+        sr = out["stage_roofline"]
+        bound_ms = ((270.7e9 + 376.8e9) * (args.seconds / 30.0) * B / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
+                    + sr.get("decode", {}).get("bytes_per_step", 0) * steps_done / (HBM_PEAK_GBS * 1e9) * 1e3)
+        out["roofline"]["whole_pass_frac"] = round(bound_ms / ms_step, 4)
+        out["roofline"]["whole_pass_bound_ms"] = round(bound_ms, 2)
+        out["roofline"]["serial_inclusive_value"] = out["serial_inclusive_value"]
+        out["roofline"]["decode_structure"] = {"fused_qkv_attention": bool(fused_qa), "chain": chain_mode, "dependent_launches_per_layer": launches_per_layer}
         if extras:
             out["batches"] = extras
     model.close()

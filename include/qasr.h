@@ -201,8 +201,14 @@ int qasr_batch_timings(qasr_engine* e, float ms[5], int32_t* n_steps);
  * `which` over the last run measured with HIP events on the engine stream, plus its launch count
  * and algorithmic bytes per launch.  which: 0 = decode-step weight-streaming GEMV group,
  * 1 = decode attention, 2 = LM head; 3 / 4 = prompt-pass QKV / gate-up GEMM, 5 = prompt attention of one layer (bytes_per_launch
- * then holds FLOPs; causal count for 5). */
+ * then holds FLOPs; causal count for 5).  The probes time what the step launches: where the step runs the q|k|v projection and the attention
+ * of a layer as ONE launch (qasr_decode_structure), 1 is that launch (K / V rows + the q|k|v weights) and 0 the three linears left. 
+ * 6 / 7: diagnostic phase stamps of the persistent launches (stderr). */
 int qasr_kernel_probe(qasr_engine* e, int which, int reps, float* avg_ms, double* bytes_per_launch);
+/* How the decode step of the CURRENT batch is launched (csrc/decoder.hip run_decode_step): *fused_qa = 1 when a layer's q|k|v projection and
+ * attention are one launch (csrc/dec_qa.hip), *chain = the `chain` knob where it applies, else 0; *launches_per_layer = dependent launches per
+ * decoder layer (5 when neither applies).  No reference counterpart. */
+int qasr_decode_structure(qasr_engine* e, int* fused_qa, int* chain, int* launches_per_layer);
 /* Diagnostic: the MFMA GEMM the encoder / prompt pass / wav2vec2 path are built on, by itself.  out[M][N] (f32, host) =
  * A[M][K] . W[N][K]^T + bias[N] with bf16 operands (host arrays of bf16 bit patterns), f32 accumulation, f32 bias (may be
  * NULL).  form: 0 = 128x128 double-buffered, 1 = 128x128 single LDS buffer, 2 = 256x256 ping-pong (csrc/gemm_p8.h),
@@ -251,6 +257,12 @@ int qasr_dp_collect(qasr_dp* dp, int64_t ticket, int32_t* tokens, int32_t* lens)
  * is also seeded once from the environment variable QASR_<KEY IN UPPER CASE>.  No reference counterpart.
  * QASR_ERR_INVALID: unknown key. */
 int qasr_set_tuning(const char* key, int value);
+/* An engine normally has its GPU to itself while a call runs, and its decode step may then use launches whose workgroups wait for each
+ * other inside the launch (csrc/dec_qa.hip: q|k|v projection + attention in one launch; every wait is bounded and ends in QASR_ERR_HIP,
+ * never in a hang).  Such a launch needs its whole grid resident at once: an engine that runs concurrently with OTHER engines on the same
+ * GPU (qasr_dp_* with a device listed more than once sets this itself) must be marked shared = 1 and then keeps to ordinary launches.
+ * No reference counterpart (the reference runs one model instance per process). */
+int qasr_set_shared_device(qasr_engine* engine, int shared);
 int qasr_get_tuning(const char* key, int* value);
 
 /* ---- stage entry points (oracle diffing) -------------------------------------------------- */

@@ -414,6 +414,16 @@ int qasr_stt_vtable(qasr_engine* e, sc_stt_vtable_t* out) {
     return QASR_OK;
 }
 
+int qasr_decode_structure(qasr_engine* e, int* fused_qa, int* chain, int* launches_per_layer) {
+    if (!e || !fused_qa || !chain || !launches_per_layer) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->decode_structure(fused_qa, chain, launches_per_layer));
+}
+
+int qasr_set_shared_device(qasr_engine* e, int shared) {
+    if (!e) return QASR_ERR_INVALID;
+    QASR_GUARD(e, e->impl->set_shared_device(shared != 0));
+}
+
 int qasr_set_tuning(const char* key, int value) {
     if (!key) return QASR_ERR_INVALID;
     return qasr::tuning_set(key, value) ? QASR_OK : QASR_ERR_INVALID;

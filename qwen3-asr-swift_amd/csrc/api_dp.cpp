@@ -61,6 +61,9 @@ int qasr_dp_create(const char* model_dir, const qasr_config* cfg, const int32_t*
         }
         dp->engines.push_back(e);
     }
+    // engines that share a GPU run concurrently (qasr_dp_submit lanes): no launch of theirs may need its whole grid resident
+    for (int i = 0; i < n_devices; ++i)
+        if (std::count(devices, devices + n_devices, devices[i]) > 1) qasr_set_shared_device(dp->engines[(size_t)i], 1);
     dp->last_ms.assign((size_t)n_devices, 0.f);
     dp->lanes.resize((size_t)n_devices);
     *out = dp.release();

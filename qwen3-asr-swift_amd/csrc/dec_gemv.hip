@@ -123,7 +123,10 @@ struct DecGemv2Args {
 // EARLYW (host: at most 8 batch rows): the weight stream is requested WITHOUT waiting for the activation rows.  With a full batch that
 // order loses in the real step (see mask_x below); with a few rows X is a couple of KB, nothing queues behind it, and the launch is the
 // serial chain  X back (1.4 us) -> weights requested -> weights back (1.9 us)  that this overlaps (in-kernel stamps at 1 clip, round 3).
-template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false, bool EARLYW = false>
+// NTW: weight fragments by non-temporal loads (a template parameter: as a run-time branch hipcc merged the two load blocks and dropped the
+// hint, round 2); A/B in profiles/r04_ab_gemv_nt.txt
+typedef __attribute__((ext_vector_type(4))) unsigned gemv_u32x4;
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false, bool EARLYW = false, bool NTW = false>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     DecGemvArgs a = a2.g;
@@ -184,7 +187,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
         // instruction reads 1 KiB contiguous (see pack_mfma_a_kernel)
         const bf16_t* wp = a.Wp + ((long)(n0 / 16 + t) * (K / 32)) * 512 + lane * 8;
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) w[t][i] = *reinterpret_cast<const uint4*>(wp + (long)(wave + WAVES * i) * 512);
+        for (int i = 0; i < KSW; ++i) {
+            if constexpr (NTW) {
+                const gemv_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gemv_u32x4*>(wp + (long)(wave + WAVES * i) * 512));
+                w[t][i] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                w[t][i] = *reinterpret_cast<const uint4*>(wp + (long)(wave + WAVES * i) * 512);
+            }
+        }
     }
     uint2 rsd[NT][NB];
     if constexpr (EPI == DEC_EPI_RESID) {
@@ -362,9 +372,15 @@ static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
     if constexpr (lds > 156 * 1024) {
         return false;
     } else {
-        auto kern = decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL, EARLYW>;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
-        hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), a2.row_groups > 1 ? a2.row_groups : 1), dim3(WAVES * 64), lds, s, a2);
+        auto go = [&](auto kern) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
+            hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), a2.row_groups > 1 ? a2.row_groups : 1), dim3(WAVES * 64), lds, s, a2);
+        };
+        // non-temporal weight loads: only the plain full-tile instantiations carry the variant (EPI LOGITS is the generic head, untouched)
+        if constexpr (!PARTIAL && EPI != DEC_EPI_LOGITS) {
+            if (tuning().gemv_nt) { go(decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL, EARLYW, true>); return true; }
+        }
+        go(decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL, EARLYW, false>);
         return true;
     }
 }

@@ -28,7 +28,10 @@ struct LmHeadArgs {
     int diag;               // 1: diagnostic build of the loop without LDS reads / MFMA (wrong results, timing only)
 };
 
-template <int K, int NB>
+typedef __attribute__((ext_vector_type(4))) unsigned lmh_u32x4;
+// NTW: the weight stream (read once per step, 311 MB) by non-temporal loads -- a TEMPLATE parameter: as a run-time branch hipcc merged the
+// two load blocks and dropped the hint (round 2); profiles/r04_ab_gemv_nt.txt
+template <int K, int NB, bool NTW>
 __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int KCH = K / 8, XSTRIDE = 2 * K + 16, NC = K / (32 * LMH_CH);   // chunks per tile
@@ -45,7 +48,14 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
         const int tile = gw + (item / NC) * total_waves, ch = item % NC;
         const bf16_t* wp = a.W + ((long)tile * (K / 32) + ch * LMH_CH) * 512 + lane * 8;   // packed, see pack_mfma_a_kernel
 #pragma unroll
-        for (int i = 0; i < LMH_CH; ++i) w[i] = *reinterpret_cast<const uint4*>(wp + i * 512);
+        for (int i = 0; i < LMH_CH; ++i) {
+            if constexpr (NTW) {
+                const lmh_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const lmh_u32x4*>(wp + i * 512));
+                w[i] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                w[i] = *reinterpret_cast<const uint4*>(wp + i * 512);
+            }
+        }
     };
     if (nitems > 0) issue(wa, 0);
     // ---- stage + RMSNorm the batch rows, 16 rows per pass (row on 32 adjacent lanes) --------------------
@@ -171,9 +181,12 @@ static int lmh_grid() {
 template <int K, int NB>
 static void lm_head_go(const LmHeadArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)NB * 16 * (2 * K + 16);
-    auto kern = lm_head_kernel<K, NB>;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
-    hipLaunchKernelGGL(kern, dim3(lmh_grid()), dim3(LMH_WAVES * 64), lds, s, a);
+    auto go = [&](auto kern) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
+        hipLaunchKernelGGL(kern, dim3(lmh_grid()), dim3(LMH_WAVES * 64), lds, s, a);
+    };
+    if (tuning().lmh_nt) go(lm_head_kernel<K, NB, true>);
+    else go(lm_head_kernel<K, NB, false>);
 }
 
 bool lm_head_supported(int N, int K) { return (K == 1024 || K == 2048) && N % 16 == 0 && N / 16 >= 512 * LMH_WAVES; }

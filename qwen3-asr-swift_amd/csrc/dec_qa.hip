@@ -10,10 +10,17 @@
 // owns attention unit (batch row g / 8, kv head g % 8).  The arithmetic is decode_gemv2_kernel's and decode_attention_mfma_kernel's, chunk for
 // chunk and wave for wave: same bits as the two launches (tests/test_gpu_chain.py).
 //
-// vmcnt is one in-order counter for loads and stores (gfx9): a wave that drains its stores, or waits for a poll, waits for every older
-// load of its own.  So wave 0 -- epilogue stores, drain, signal, poll -- keeps no K / V request in flight until the hand-off is over: its
-// early requests all read ONE cached 16 bytes (so that every wave runs the same unconditional request code and hipcc's counted waits stay
-// exact), and it requests its real chunks after the poll.  Waves 1..7 hold their chunks from the start.
+// Request schedule (second form; the first one requested every chunk before the projection and measured the projection's rows staged only at
+// 9.3 us, profiles/r04_stamps_chain.txt: a wave blocks at ISSUE while its CU's request queue drains at the CU's HBM share, so 32 chunk requests
+// per wave in front of the projection put the whole stream in front of it):
+//   entry              context length, norm weights, activation rows, weight tile, then ONLY the K half of each wave's first chunk (8 KB per wave:
+//                      the stream starts, the queue never fills)
+//   projection summed  waves 1..7: the rest of their two chunks (V of the first, K and V of the second) -- nothing of theirs is on the critical
+//                      path any more; wave 0: epilogue stores, drain, signal, poll
+//   hand-off over      wave 0 reads the token's own q / k / v rows, norms + ropes them ONCE for the workgroup (shared LDS image; the stand-alone
+//                      kernel does it per wave to save a barrier, same values), appends k / v, then requests the rest of its chunks
+// vmcnt is one in-order counter for loads and stores (gfx9): a wave that drains its stores, or waits for a poll or for the own rows, waits for
+// every older load of its own -- which is why wave 0 holds nothing but its first K half (landed long before its drain) until the rows are in.
 #include "dec_chain_dev.h"
 #include "dec_rope.h"
 #include <mutex>
@@ -75,7 +82,6 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     pos = has_att ? __builtin_amdgcn_readfirstlane(pos) : 1;         // wave-uniform by construction: scalar loop bounds below
     const int nchunks = (pos + 31) >> 5;
     uint4 kreg[UNR][2 * KS], vreg[UNR][DT];
-    const bool dummy = wave == 0 || !has_att;                         // see the file header
     int ch_early[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -83,16 +89,21 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         ch = ch < nchunks - 1 ? ch : nchunks - 1;                     // chunks past the context re-read the last one (cache hits), skipped in the sweep
         ch_early[u] = ch < max_chunk ? ch : max_chunk;
     }
-    // K chunks now; the V chunks once the activation rows have left their registers for LDS (register budget: 256 per thread)
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
+    // unconditional request code (addresses selected, not branches), so that hipcc's counted waits for the projection's operands stay exact
+    auto request_k = [&](int u) {
         const bf16_t* kr = kb + ((long)ch_early[u] * 32 + fr) * HD;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(dummy ? kdummy : kr + (long)h * 16 * HD + ks * 32);
-    }
+                kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(has_att ? kr + (long)h * 16 * HD + ks * 32 : kdummy);
+    };
+    auto request_v = [&](int u) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            vreg[u][dt] = *reinterpret_cast<const uint4*>(has_att ? vfb + ((long)ch_early[u] * DT + dt) * 512 : kdummy);
+    };
+    request_k(0);
     if (tid < 128) reinterpret_cast<uint4*>(dsm + L_NORM)[tid] = nw;
     __syncthreads();
 
@@ -105,14 +116,8 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         }
     {
         f32x4 acc[1][NB];
-        auto issue_v = [&]() {
-#pragma unroll
-            for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-                    vreg[u][dt] = *reinterpret_cast<const uint4*>(dummy ? kdummy : vfb + ((long)ch_early[u] * DT + dt) * 512);
-        };
-        chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1, issue_v);
+        chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1);
+        if (wave != 0) { request_v(0); request_k(1); request_v(1); }
         if (wave == 0) {
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
@@ -149,72 +154,82 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
                 vreg[u][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch * DT + dt) * 512);
         }
     };
-    if (wave == 0) issue(0, nchunks);
-    bf16_t* s_q = reinterpret_cast<bf16_t*>(s_x);                                       // [WAVES][REP][HD]
+    bf16_t* s_q = reinterpret_cast<bf16_t*>(s_x);                                       // [REP][HD]  (one image for the workgroup)
     float* s_o = reinterpret_cast<float*>(s_x + WAVES * REP * HD * 2);                  // [WAVES][REP][HD]
     float* s_m = s_o + WAVES * REP * HD;                                                // [WAVES][REP]
     float* s_l = s_m + WAVES * REP;
     float* s_new = s_l + WAVES * REP;                                                   // [REP]
     float* s_vn = s_new + REP;                                                          // [HD]
-    // the token's own rows: handed-off bytes -> sc1 loads, one dword (two elements) per lane, then a lane permute puts element `lane`
-    // and element `lane + 64` on every lane like the two-byte loads of the stand-alone kernel
-    const bf16_t* row = a.qkv + (long)b * QA_NQKV;
-    unsigned wq[REP], wk, wv;
+    if (wave == 0) {
+        // the token's own rows: handed-off bytes -> sc1 loads, one dword (two elements) per lane, then a lane permute puts element `lane`
+        // and element `lane + 64` on every lane like the two-byte loads of the stand-alone kernel
+        const bf16_t* row = a.qkv + (long)b * QA_NQKV;
+        unsigned wq[REP], wk, wv;
 #pragma unroll
-    for (int r = 0; r < REP; ++r) wq[r] = ld4_sc1(row + (long)(kvh * REP + r) * HD + 2 * lane);
-    wk = ld4_sc1(row + (long)(QA_HEADS + kvh) * HD + 2 * lane);
-    wv = ld4_sc1(row + (long)(QA_HEADS + QA_KVH + kvh) * HD + 2 * lane);
-    const float rc = a.rope_cos[(long)b * HALF + lane], rs = a.rope_sin[(long)b * HALF + lane];
-    const float w1 = bf16_to_f32(a.qn_w[lane]), w2 = bf16_to_f32(a.qn_w[lane + HALF]);
-    const float kw1 = bf16_to_f32(a.kn_w[lane]), kw2 = bf16_to_f32(a.kn_w[lane + HALF]);
-    auto pick = [&](unsigned w, int src_lane) {
-        const unsigned v = (unsigned)__shfl((int)w, src_lane, 64);
-        return (bf16_t)((lane & 1) ? v >> 16 : v & 0xffffu);
-    };
-    if constexpr (ST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    QA_STAMP(5, 64);
-    float x1[REP], x2[REP];
+        for (int r = 0; r < REP; ++r) wq[r] = ld4_sc1(row + (long)(kvh * REP + r) * HD + 2 * lane);
+        wk = ld4_sc1(row + (long)(QA_HEADS + kvh) * HD + 2 * lane);
+        wv = ld4_sc1(row + (long)(QA_HEADS + QA_KVH + kvh) * HD + 2 * lane);
+        const float rc = a.rope_cos[(long)b * HALF + lane], rs = a.rope_sin[(long)b * HALF + lane];
+        const float w1 = bf16_to_f32(a.qn_w[lane]), w2 = bf16_to_f32(a.qn_w[lane + HALF]);
+        const float kw1 = bf16_to_f32(a.kn_w[lane]), kw2 = bf16_to_f32(a.kn_w[lane + HALF]);
+        auto pick = [&](unsigned w, int src_lane) {
+            const unsigned v = (unsigned)__shfl((int)w, src_lane, 64);
+            return (bf16_t)((lane & 1) ? v >> 16 : v & 0xffffu);
+        };
+        float x1[REP], x2[REP];
 #pragma unroll
-    for (int r = 0; r < REP; ++r) { x1[r] = bf16_to_f32(pick(wq[r], lane >> 1)); x2[r] = bf16_to_f32(pick(wq[r], 32 + (lane >> 1))); }
-    const float kx1 = bf16_to_f32(pick(wk, lane >> 1)), kx2 = bf16_to_f32(pick(wk, 32 + (lane >> 1)));
-    const bf16_t vown[2] = {pick(wv, lane >> 1), pick(wv, 32 + (lane >> 1))};
-    float qa[REP][2];
+        for (int r = 0; r < REP; ++r) { x1[r] = bf16_to_f32(pick(wq[r], lane >> 1)); x2[r] = bf16_to_f32(pick(wq[r], 32 + (lane >> 1))); }
+        const float kx1 = bf16_to_f32(pick(wk, lane >> 1)), kx2 = bf16_to_f32(pick(wk, 32 + (lane >> 1)));
+        const bf16_t vown[2] = {pick(wv, lane >> 1), pick(wv, 32 + (lane >> 1))};
+        float qa[REP][2];
 #pragma unroll
-    for (int r = 0; r < REP; ++r) {
-        const float inv = rsqrtf(lane_sum<64>(x1[r] * x1[r] + x2[r] * x2[r]) / (float)HD + a.eps);
-        norm_rope_pair(x1[r], x2[r], w1, w2, inv, rc, rs, qa[r][0], qa[r][1]);
-        s_q[(wave * REP + r) * HD + lane] = f32_to_bf16(qa[r][0]);
-        s_q[(wave * REP + r) * HD + lane + HALF] = f32_to_bf16(qa[r][1]);
-    }
-    {
+        for (int r = 0; r < REP; ++r) {
+            const float inv = rsqrtf(lane_sum<64>(x1[r] * x1[r] + x2[r] * x2[r]) / (float)HD + a.eps);
+            norm_rope_pair(x1[r], x2[r], w1, w2, inv, rc, rs, qa[r][0], qa[r][1]);
+            s_q[r * HD + lane] = f32_to_bf16(qa[r][0]);
+            s_q[r * HD + lane + HALF] = f32_to_bf16(qa[r][1]);
+        }
         const float inv = rsqrtf(lane_sum<64>(kx1 * kx1 + kx2 * kx2) / (float)HD + a.eps);
         float k1, k2;
         norm_rope_pair(kx1, kx2, kw1, kw2, inv, rc, rs, k1, k2);
-        if (wave == WAVES - 1) {
-            bf16_t* dk = cache.k + cache.off(b, kvh, pos);
-            dk[lane] = f32_to_bf16(k1);
-            dk[lane + HALF] = f32_to_bf16(k2);
-        }
+        bf16_t* dk = cache.k + cache.off(b, kvh, pos);
+        dk[lane] = f32_to_bf16(k1);
+        dk[lane + HALF] = f32_to_bf16(k2);
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
             const float d = lane_sum<64>(qa[r][0] * k1 + qa[r][1] * k2);
-            if (wave == WAVES - 1 && lane == 0) s_new[r] = d * a.scale;
+            if (lane == 0) s_new[r] = d * a.scale;
         }
         bf16_t* dvf = cache.vf + cache.off(b, kvh, 0);
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = lane + 64 * ii;
-            s_vn[i] = bf16_to_f32(vown[ii]);                         // every wave writes the same value
-            if (wave == WAVES - 2) dvf[qa_vfrag_index<HD>(pos, i)] = vown[ii];
+            s_vn[i] = bf16_to_f32(vown[ii]);
+            dvf[qa_vfrag_index<HD>(pos, i)] = vown[ii];
+        }
+        // the rest of wave 0's chunks (its first K half came in with everybody's)
+        if (wave < nchunks) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vreg[0][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[0] * DT + dt) * 512);
+        }
+        if (wave + WAVES < nchunks) {
+            const bf16_t* kr = kb + ((long)ch_early[1] * 32 + fr) * HD;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kreg[1][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vreg[1][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[1] * DT + dt) * 512);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if constexpr (ST) { if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    QA_STAMP(5, 64);
     mfma_bf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         uint4 u = make_uint4(0, 0, 0, 0);
-        if (fr < REP) u = *reinterpret_cast<const uint4*>(&s_q[(wave * REP + fr) * HD + ks * 32 + g * 8]);
+        if (fr < REP) u = *reinterpret_cast<const uint4*>(&s_q[fr * HD + ks * 32 + g * 8]);
         qf[ks] = __builtin_bit_cast(mfma_bf16x8, u);
     }
     f32x4 o[DT];

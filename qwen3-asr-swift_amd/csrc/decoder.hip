@@ -556,6 +556,28 @@ void Engine::decode_gemv(DecEpi epi, const DecGemvArgs& a, const QuantImg& qi, c
     else decode_gemv_fused_launch(epi, a, norm_w, norm_w ? cfg_.rms_eps : 0.f, norm_w ? h : nullptr, s);
 }
 
+int Engine::step_chain(int r0, int nr) const {
+    const int hd = cfg_.head_dim;
+    return (!decw_.quant && r0 == 0 && !stamp_buf_ && !shared_device_ &&
+            decode_chain_supported(cfg_.hidden, cfg_.heads * hd, cfg_.inter, (cfg_.heads + 2 * cfg_.kv_heads) * hd, nr)) ? tuning().chain : 0;
+}
+bool Engine::step_qa(int r0, int nr, int chain) const {
+    const int hd = cfg_.head_dim;
+    return !decw_.quant && r0 == 0 && !stamp_buf_ && !shared_device_ && chain < 3 && tuning().qa &&
+           decode_qa_supported(cfg_.hidden, cfg_.heads, cfg_.kv_heads, hd, nr, max_ctx_) && (cfg_.heads + 2 * cfg_.kv_heads) * hd == 4096;
+}
+void Engine::decode_structure(int* fused_qa, int* chain, int* launches_per_layer) {
+    if (!finalized_ || batch_ <= 0) throw std::runtime_error("decode_structure needs a prepared batch");
+    const int rows = decode_group_rows();
+    const bool whole = rows == batch_;
+    const int c = whole ? step_chain(0, rows) : 0;
+    const bool q = whole && step_qa(0, rows, c);
+    *chain = c;
+    *fused_qa = q ? 1 : 0;
+    // five launches: q|k|v, attention, o-proj, gate|up, down
+    *launches_per_layer = c == 3 ? 2 : 5 - (q ? 1 : 0) - (c == 1 ? 1 : c == 2 ? 2 : 0);
+}
+
 // One decode step for batch rows [r0, r0 + nr) on stream s.  Rows are independent, so a step can be
 // issued as several row groups on parallel graph branches (see decode_loop).
 void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipStream_t s, bool with_head) {
@@ -568,9 +590,8 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     const GreedyState gs = greedy_rows(r0);
     // chain > 0: a layer's linears run as one persistent launch (dec_chain.hip) wherever it has an instantiation: the float 0.6B geometry,
     // the whole batch in one row group (the arrival counters belong to one step of one engine), up to 32 rows
-    const int chain = (!decw_.quant && r0 == 0 && !stamp_buf_ && decode_chain_supported(H, nq, I, nh * hd, nr)) ? tuning().chain : 0;
-    const bool qa = !decw_.quant && r0 == 0 && !stamp_buf_ && chain < 3 && tuning().qa &&
-                    decode_qa_supported(H, cfg_.heads, cfg_.kv_heads, hd, nr, max_ctx_) && nh * hd == 4096;
+    const int chain = step_chain(r0, nr);
+    const bool qa = step_qa(r0, nr, chain);
     if (chain || qa) decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
@@ -957,17 +978,22 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     const int rows = decode_group_rows();
     const PromptW probe_w = (which == 3 || which == 4) ? prompt_weights(0, s) : PromptW{};
     long probe_layer = 0;
+    const int probe_chain = rows == batch_ ? step_chain(0, rows) : 0;
+    const bool probe_qa = rows == batch_ && step_qa(0, rows, probe_chain);
+    hipEvent_t* probe_ev = nullptr;            // set per timed launch of the fused probe: the counter memset stays outside the event pair
     auto body = [&]() {
         DecGemvArgs a{};
         a.B = rows;
         auto gemv = [&](DecEpi epi, const QuantImg& qi, const bf16_t* norm_w) { decode_gemv(epi, a, qi, norm_w, d_dh_.as<bf16_t>(), s); };
         if (which == 0) {
-            // the same four launches as run_decode_step (residual epilogues write a scratch row block), one LAYER AFTER THE OTHER like
+            // the same launches as run_decode_step (residual epilogues write a scratch row block), one LAYER AFTER THE OTHER like
             // the step: a layer's 31 MB come back only after the other layers' 0.85 GB went through the caches, so every launch streams
             // its weights from HBM as in situ (one layer in a loop would sit in the Infinity Cache and time 15 % short)
             const DecLayerW& L = decw_.layers[(size_t)(probe_layer++ % cfg_.dec_layers)];
-            a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
-            gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
+            if (!probe_qa) {                   // with q|k|v + attention as one launch the projection belongs to probe 1
+                a.W = L.wqkv; a.Wp = L.wqkv_p; a.X = d_dx_.as<bf16_t>(); a.N = nh * hd; a.K = H; a.out = d_dqkv_.as<bf16_t>();
+                gemv(DEC_EPI_BF16, L.qkv_q, L.ln1);
+            }
             a.W = L.wo; a.Wp = L.wo_p; a.X = d_dattn_.as<bf16_t>(); a.N = H; a.K = nq; a.out = d_dh_.as<bf16_t>();
             gemv(DEC_EPI_RESID, L.o_q, nullptr);
             a.W = L.wgu; a.Wp = L.wgu_p; a.X = d_dx_.as<bf16_t>(); a.N = 2 * I; a.K = H; a.out = d_dact_.as<bf16_t>();
@@ -976,6 +1002,18 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
             gemv(DEC_EPI_RESID, L.down_q, nullptr);
         } else if (which == 1) {
             const RopeRows rr = rope_rows(0);
+            if (probe_qa) {
+                // the fused launch on layer after layer: its q|k|v weights AND its K / V rows come from HBM every time, as in the step
+                const int l = (int)(probe_layer++ % cfg_.dec_layers);
+                const DecLayerW& Lq = decw_.layers[(size_t)l];
+                KVLayout kvl{kcache_[l]->as<bf16_t>(), nullptr, max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
+                decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
+                DecQaArgs q{d_dx_.as<bf16_t>(), Lq.ln1, Lq.wqkv_p, d_dqkv_.as<bf16_t>(), gstate_.ctx_len, Lq.qn, Lq.kn, rr.cos_rows, rr.sin_rows,
+                            kvl, d_dattn_.as<bf16_t>(), rows, cfg_.rms_eps, 1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), 0u, d_err_flag_};
+                if (probe_ev) QASR_HIP(hipEventRecord(probe_ev[0], s));
+                decode_qa_launch(q, s);
+                if (probe_ev) QASR_HIP(hipEventRecord(probe_ev[1], s));
+            } else
             decode_attention_launch(d_dqkv_.as<bf16_t>(), gstate_.ctx_len, rows, cfg_.heads, cfg_.kv_heads, hd, L.qn,
                                     L.kn, cfg_.rms_eps, rr.cos_rows, rr.sin_rows, kv, d_dattn_.as<bf16_t>(), s);
         } else if (which == 3) {      // prompt-pass QKV GEMM shape (M = packed prompt rows, N = 4096, K = 1024)
@@ -993,7 +1031,20 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     };
     for (int i = 0; i < 3; ++i) body();
     float ms = 0;
-    if (which == 1) {
+    if (which == 1 && probe_qa) {
+        // the fused launch, one event pair per launch (set inside body around the launch itself)
+        std::vector<hipEvent_t> ev(2 * reps);
+        for (auto& e : ev) QASR_HIP(hipEventCreate(&e));
+        for (int i = 0; i < reps; ++i) { probe_ev = &ev[2 * i]; body(); }
+        probe_ev = nullptr;
+        QASR_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < reps; ++i) {
+            float t = 0;
+            QASR_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+            ms += t;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    } else if (which == 1) {
         // in-situ-like timing of the single attention kernel: every timed launch is preceded by an untimed
         // weight-streaming launch (as in the real step, which evicts the query rows / rope table from the
         // near caches), and bracketed by its own event pair on the engine stream
@@ -1175,8 +1226,11 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
     double bytes = 0;
     // weight bytes per element: 2 (bf16) or bits / 8 + scale and bias per 64 elements
     const double wbytes = !decw_.quant ? 2.0 : cfg_.bits / 8.0 + 2.0 * (decw_.embed_raw.sb_f32 ? 4.0 : 2.0) / 64.0;
-    if (which == 0) bytes = wbytes * ((double)nh * hd * H + (double)H * nq + 2.0 * I * H + (double)H * I);
-    else if (which == 1) { for (int b = 0; b < rows; ++b) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)ctx[b]; }
+    if (which == 0) bytes = wbytes * ((probe_qa ? 0.0 : (double)nh * hd * H) + (double)H * nq + 2.0 * I * H + (double)H * I);
+    else if (which == 1) {
+        for (int b = 0; b < rows; ++b) bytes += 2.0 * 2.0 * cfg_.kv_heads * hd * (double)ctx[b];
+        if (probe_qa) bytes += wbytes * (double)nh * hd * H;
+    }
     else if (which == 3) bytes = 2.0 * (double)n_pos_ * nh * hd * H;          // FLOPs for the GEMM probes
     else if (which == 4) bytes = 2.0 * (double)n_pos_ * 2 * I * H;
     else if (which == 5) {      // causal FLOPs: per clip and head 4 hd sum_t (t + 1) = 2 hd T (T + 1)

@@ -109,6 +109,11 @@ public:
                     float* avg_ms);
     void kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_launch);
     int batch_size() const { return batch_; }
+    void decode_structure(int* fused_qa, int* chain, int* launches_per_layer);
+    int step_chain(int r0, int nr) const;           // the chain knob where the persistent launch applies to rows [r0, r0 + nr), else 0
+    bool step_qa(int r0, int nr, int chain) const;  // q|k|v + attention as one launch for those rows
+    // several engines run concurrently on this GPU: no launch may rely on its whole grid being resident (dec_chain.hip, dec_qa.hip)
+    void set_shared_device(bool shared) { if (shared != shared_device_) { shared_device_ = shared; drop_graph(); } }
     void require_asr(const char* what) const {
         if (cfg_.classify_num > 0) throw std::runtime_error(std::string(what) + ": this engine is a forced aligner (no LM head / decode state)");
     }
@@ -255,6 +260,7 @@ private:
     DevBuf d_vt_;
     DevBuf d_px_, d_ph_, d_pqkv_, d_pqr_, d_pattn_, d_pact_;   // prefill (packed prompt positions)
     DevBuf d_dx_, d_dh_, d_dqkv_, d_dattn_, d_dact_, d_logits_, d_part_val_, d_part_idx_;   // decode rows
+    bool shared_device_ = false;
     unsigned long long* qa_dbg_ = nullptr;
     unsigned long long* chain_dbg_ = nullptr;                  // diagnostic stamps of the middle layer's chain launch (kernel_probe 6)
     DevBuf d_chain_ctr_;                                       // arrival counters of the persistent layer launch (dec_chain.h)

@@ -39,6 +39,12 @@ ClipPlan Engine::plan_clip(const qasr_config& cfg, long n, int extra_prompt) {
 }
 
 Engine::Engine(const qasr_config& cfg) : cfg_(cfg) {
+    if (cfg_.max_batch <= 0) throw std::invalid_argument("max_batch must be positive");
+    // the decode step holds the batch rows of a launch in at most four 16-row MFMA tiles (dec_gemv.hip, dec_lmhead.hip, dec_quant.hip): refuse a
+    // capacity the step could not serve here, not at the first qasr_batch_run.  Larger jobs go through the engine in passes (qasr_dp_*,
+    // qasr/transcribe_batch.py); the forced aligner has no decode step and is not bounded by this.
+    if (cfg_.classify_num == 0 && cfg_.max_batch > 64)
+        throw std::invalid_argument("max_batch " + std::to_string(cfg_.max_batch) + " exceeds the decode step's 64 batch rows per engine; run larger jobs in passes of <= 64 clips (qasr_dp_transcribe_batch slices a block over its engines)");
     QASR_HIP(hipSetDevice(cfg_.device));
     QASR_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     mel_tables_.build(cfg_.fft_scale);

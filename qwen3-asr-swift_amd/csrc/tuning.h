@@ -13,10 +13,12 @@ struct Tuning {
     int gemv_w1024 = 8;      // waves per workgroup for K = 1024 (8 x 4 k-steps | 4 x 8)
     int gemv_partial = 1;    // fewer than 16 batch rows: norm GEMVs skip the normalisation of rows past the end (own instantiation) | 0 off
     int gemv_earlyw = 1;     // at most 8 batch rows: the weight stream requested without waiting for the activation rows | 0 after them (as at 16+ rows)
+    int gemv_nt = 0;         // decode GEMV weight fragments: 1 non-temporal loads (template parameter) | 0 default cache policy
+    int lmh_nt = 1;          // LM head weight stream: 1 non-temporal loads | 0 default
     int gemv_wide = 1;       // K = 6144 (1.7B down-projection): 1 two-phase LDS image, weights in registers (dec_gemv_wide.hip) | 0 generic kernel
     int chain = 0;           // decode layer's linears as one persistent launch with in-launch hand-offs (dec_chain.hip): 0 five launches per layer |
                              // 1 o-proj -> gate|up | 2 ... -> down | 3 ... -> the next layer's q|k|v (two launches per layer: attention + chain)
-    int qa = 0;              // q|k|v projection + decode attention of a layer as one launch, K / V requested before the projection (dec_qa.hip): 1 | 0 two launches
+    int qa = 1;              // q|k|v projection + decode attention of a layer as one launch, K / V requested before the projection (dec_qa.hip): 1 | 0 two launches
     int chain_proto = 0;     // chain arrival counters: 0 sharded (add to one of 8, poll all 8) | 1 replicated (add to all 8, poll one)
     int chain_pf = 0;        // chain weight requests: 0 every phase's tiles at kernel entry | 1 staged (first phase first)
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)

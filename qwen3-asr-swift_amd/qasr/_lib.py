@@ -114,6 +114,8 @@ SIGNATURES = {
     "qasr_batch_timings": (C.c_int, [_E, _F, _I]),
     "qasr_kernel_probe": (C.c_int, [_E, C.c_int, C.c_int, _F, _P(C.c_double)]),
     "qasr_gemm_probe": (C.c_int, [_E, _P(C.c_uint16), _P(C.c_uint16), _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]),
+    "qasr_set_shared_device": (C.c_int, [_E, C.c_int]),
+    "qasr_decode_structure": (C.c_int, [_E, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "qasr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "qasr_get_tuning": (C.c_int, [C.c_char_p, _P(C.c_int)]),
     "qasr_num_mel_frames": (C.c_int, [C.c_size_t]),

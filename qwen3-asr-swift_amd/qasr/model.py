@@ -233,6 +233,12 @@ class Qwen3ASRModel:
         self._check(self.lib.qasr_batch_timings(self.h, ms, C.byref(steps)))
         return list(ms), steps.value
 
+    def decode_structure(self):
+        """(fused_qa, chain, dependent launches per layer) of the current batch's decode step (qasr_decode_structure)."""
+        q, c, n = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.qasr_decode_structure(self.h, C.byref(q), C.byref(c), C.byref(n)))
+        return q.value, c.value, n.value
+
     def kernel_probe(self, which, reps=20):
         ms, by = C.c_float(), C.c_double()
         self._check(self.lib.qasr_kernel_probe(self.h, which, reps, C.byref(ms), C.byref(by)))

@@ -37,6 +37,9 @@ def pick(sub):
             return r[4], r[1]
     return None, 0
 att, n_att = pick("decode_attention")
+qa, n_qa = pick("decode_qa_kernel")
+if n_qa:                                        # q|k|v + attention as one launch: the per-layer count comes from it
+    n_att = n_qa
 lm, _ = pick("lm_head_kernel")
 sys.path.insert(0, root)
 import bench                                    # kernel_source_stamp(): the traffic figure is tied to the kernels it was measured on
@@ -45,6 +48,9 @@ n_layers_steps = n_att
 out = {"kernel_source_stamp": bench.kernel_source_stamp(), "gemv_source_stamp": bench.kernel_source_stamp(bench.GEMV_SOURCES), "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0 --decode-tokens 16 "
                  "--no-cpu-baseline --no-extras`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128-B request)",
        "decode_attention_bytes": att, "decode_attention_launches": n_att,
+       "fused_qa": bool(n_qa), "qa_source_stamp": bench.kernel_source_stamp(bench.QA_SOURCES), "decode_qa_bytes": qa,
+       # the fused launch streams the same K / V rows plus the q|k|v weights (4096 x 1024 bf16)
+       "decode_qa_algorithmic_bytes_at_that_context": 32 * 2 * 8 * 128 * 2 * (406 + 7.0) + 4096 * 1024 * 2,
        "layer_gemv_group_bytes": gemv / n_att if n_att else None, "lm_head_bytes": lm,
        # 16-token run, 32 rows x 30 s: contexts 406 .. 406+14 over the 15 decode steps -> mean 413; K+V rows of 8 kv heads x 128 x 2 B
        "decode_attention_algorithmic_bytes_at_that_context": 32 * 2 * 8 * 128 * 2 * (406 + 7.0)}

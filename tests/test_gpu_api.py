@@ -100,6 +100,26 @@ def test_errors_and_capacity(model):
                                      lens.ctypes.data_as(C.POINTER(C.c_int32))) == 6   # QASR_ERR_EMPTY_AUDIO
 
 
+def test_decode_capacity_is_checked_at_create():
+    """The decode step holds a launch's batch rows in at most four 16-row tiles: a capacity beyond 64 rows is refused by qasr_create with a
+    message (round 3: it was accepted and failed at the first qasr_batch_run); 64 itself is served."""
+    import gpu_util
+    with pytest.raises(RuntimeError, match="64 batch rows"):
+        gpu_util.Engine("tiny", max_batch=65)
+    with pytest.raises(RuntimeError, match="positive"):
+        gpu_util.Engine("tiny", max_batch=0)
+    e = gpu_util.Engine("tiny", max_batch=64, max_audio_seconds=2, max_new_tokens=8)
+    try:
+        e.load_state_dict(synth.synth_state_dict(QC.AUDIO_TINY, QC.TEXT_TINY, seed=3, init="stress"))
+        clips = [synth.synth_waveform(k, 0.5 + 0.02 * k) for k in range(64)]
+        out = e.transcribe_batch(clips, max_tokens=5, ignore_eos=True)
+        assert [len(t) for t in out] == [5] * 64
+        for k in (0, 17, 63):
+            assert e.transcribe_batch([clips[k]], max_tokens=5, ignore_eos=True)[0] == out[k]
+    finally:
+        e.close()
+
+
 def test_out_of_range_prompt_ids_are_refused(model):
     """context / language ids index the embedding table on the device: anything outside [0, vocab) or a negative count
     is QASR_ERR_INVALID on the host, never an out-of-bounds gather."""

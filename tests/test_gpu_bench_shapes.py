@@ -142,3 +142,29 @@ def test_32x30s_shard(rig):
             assert logits[t] >= logits.max() - tol, (i, t, float(logits[t]), float(logits.max()))
             if i + 1 < len(a[0]):
                 logits = decoder.decode_step(t, W, C.TEXT_SMALL, state, P.REFERENCE)
+
+
+def test_first_staged_batch_of_an_engine_at_full_size(rig):
+    """qasr_batch_stage right after an engine's FIRST qasr_batch_run, with DIFFERENT clips, at the bench's batch size: the events that order
+    the staged copies behind the running batch's log-mel are created by that first stage call, so the running batch could not have recorded
+    them (round-3 advisor finding: the wait was on a never-recorded event, i.e. no wait).  Both batches must equal their plain runs."""
+    from qasr.model import Qwen3ASRModel
+    a = [rig["pcm"]] + [synth.synth_waveform(k, 30.0) for k in range(1, 32)]
+    b = [synth.synth_waveform(100 + k, 29.0 - 0.2 * (k % 7)) for k in range(32)]
+    eng = rig["eng"]
+    want_a = eng.transcribe_batch(a, max_tokens=4, ignore_eos=True)
+    want_b = eng.transcribe_batch(b, max_tokens=4, ignore_eos=True)
+    assert want_a != want_b
+    m = Qwen3ASRModel.from_state_dict(rig["sd"], preset="0.6B", max_batch=32, max_audio_seconds=30, max_new_tokens=16)
+    try:
+        m.batch_begin(a, max_tokens=4, ignore_eos=True)
+        m.batch_run()
+        m.batch_stage(b)                                     # the first stage call of this engine
+        toks, lens = m.batch_tokens()
+        assert [toks[i, :lens[i]].tolist() for i in range(32)] == want_a
+        m.batch_begin_staged(max_tokens=4, ignore_eos=True)
+        m.batch_run()
+        toks, lens = m.batch_tokens()
+        assert [toks[i, :lens[i]].tolist() for i in range(32)] == want_b
+    finally:
+        m.close()
