@@ -8,6 +8,8 @@ BT = 32
 sd = synth.synth_state_dict(QC.AUDIO_SMALL, QC.TEXT_SMALL, seed=0, init="hf")
 B = BT // NE
 engines = [Qwen3ASRModel.from_state_dict(sd, preset="0.6B", max_batch=B, max_audio_seconds=30, max_new_tokens=448) for _ in range(NE)]
+for e in engines:
+    e.lib.qasr_set_shared_device(e.h, 1)      # engines that run concurrently on one GPU keep to ordinary launches (include/qasr.h)
 clips = [synth.synth_waveform(k, 30.0) for k in range(BT)]
 for i, e in enumerate(engines):
     e.batch_begin(clips[i * B:(i + 1) * B], max_tokens=128, ignore_eos=True)

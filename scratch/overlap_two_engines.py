@@ -52,6 +52,8 @@ def main():
     sd = synth.synth_state_dict(QC.AUDIO_SMALL, QC.TEXT_SMALL, seed=0, init="hf")
     cap = dict(device=0, max_batch=a.batch, max_audio_seconds=int(np.ceil(a.seconds)), max_new_tokens=448)
     engines = [Qwen3ASRModel.from_state_dict(sd, preset="0.6B", bits=16, **cap) for _ in range(a.engines)]
+    for e in engines:
+        e.lib.qasr_set_shared_device(e.h, 1)  # engines that run concurrently on one GPU keep to ordinary launches (include/qasr.h)
     clips = [synth.synth_waveform(k, a.seconds) for k in range(a.batch)]
     ref = passes(engines[0], clips, a.decode_tokens, 2)
     for e in engines[1:]:

@@ -33,8 +33,8 @@ def _ulp_tol(ref, ulps=6.0):
 
 
 @pytest.fixture(scope="module")
-def rig():
-    sd = synth.synth_state_dict(C.AUDIO_SMALL, C.TEXT_SMALL, seed=0, init="stress")
+def rig(sd_small_stress):
+    sd = sd_small_stress
     eng = gpu_util.Engine("0.6B", max_batch=32, max_audio_seconds=30, max_new_tokens=16)
     eng.load_state_dict(sd)
     W = decoder.Weights(sd)
@@ -43,7 +43,7 @@ def rig():
     with torch.no_grad():
         enc_dev = encoder.encode(mel, W, C.AUDIO_SMALL, P.DEVICE)
         enc_ref = encoder.encode(mel, W, C.AUDIO_SMALL, P.REFERENCE)
-    yield dict(eng=eng, sd=sd, W=W, pcm=pcm, mel=mel, enc_dev=enc_dev, enc_ref=enc_ref)
+    yield dict(eng=eng, sd=sd, W=W, pcm=pcm, mel=mel, enc_dev=enc_dev, enc_ref=enc_ref, oracle_cache={})
     eng.close()
 
 
@@ -62,11 +62,22 @@ def _decoder_check(r, got_emb):
     """prompt pass (T = 406) vs REFERENCE, then N_STEPS teacher-forced steps along the oracle's greedy stream."""
     eng, W = r["eng"], r["W"]
     emb = torch.from_numpy(got_emb)                      # both sides consume the device's encoder output
-    with torch.no_grad():
-        ref_logits, state, ids = decoder.prefill(emb, W, C.TEXT_SMALL, P.REFERENCE, C.TOKENS)
-        dev_logits, _, _ = decoder.prefill(emb, W, C.TEXT_SMALL, P.DEVICE, C.TOKENS)
-    assert len(ids) == 406
-    ref, dev = ref_logits.numpy(), dev_logits.numpy()
+    # the CPU side depends only on that input (the GEMM forms give bit-identical encoder outputs, test_gemm_forms_agree_bit_for_bit):
+    # computed once per distinct input and reused by the other forms -- 40 s of fp32 CPU work per evaluation
+    key = got_emb.tobytes()
+    if key not in r["oracle_cache"]:
+        with torch.no_grad():
+            ref_logits, state, ids = decoder.prefill(emb, W, C.TEXT_SMALL, P.REFERENCE, C.TOKENS)
+            dev_logits, _, _ = decoder.prefill(emb, W, C.TEXT_SMALL, P.DEVICE, C.TOKENS)
+            toks, step_logits, logits = [], [], ref_logits
+            for i in range(N_STEPS):
+                toks.append(int(torch.argmax(logits)))
+                logits = decoder.decode_step(toks[-1], W, C.TEXT_SMALL, state, P.REFERENCE)
+                step_logits.append(logits.numpy().copy())
+        r["oracle_cache"].clear()
+        r["oracle_cache"][key] = (ref_logits.numpy().copy(), dev_logits.numpy().copy(), len(ids), toks, step_logits)
+    ref, dev, n_ids, toks, step_logits = r["oracle_cache"][key]
+    assert n_ids == 406
     print(f"CPU policy-to-policy floor at T=406: max|d| {np.abs(ref - dev).max():.4f} "
           f"({np.abs(ref - dev).max() / _ulp_tol(ref, 1.0):.1f} ulps), rel-L2 {np.linalg.norm(ref - dev) / np.linalg.norm(ref):.2e}")
     got = eng.prefill_logits(got_emb)
@@ -74,17 +85,13 @@ def _decoder_check(r, got_emb):
     print(f"T=406 prompt-pass logits vs REFERENCE: max|d| {d:.4f} ({d / _ulp_tol(ref, 1.0):.1f} ulps), rel-L2 {rel:.2e}")
     assert d <= _ulp_tol(ref) and rel < 3e-2
     assert ref[int(got.argmax())] >= ref.max() - _ulp_tol(ref)
-    toks, logits = [], ref_logits
-    with torch.no_grad():
-        for i in range(N_STEPS):
-            toks.append(int(torch.argmax(logits)))
-            logits = decoder.decode_step(toks[-1], W, C.TEXT_SMALL, state, P.REFERENCE)
-            forced = eng.decode_forced([toks[-1]])[0]
-            refi = logits.numpy()
-            d, rel = np.abs(forced - refi).max(), np.linalg.norm(forced - refi) / np.linalg.norm(refi)
-            print(f"  step {i} (ctx {406 + i}): max|d| {d:.4f} ({d / _ulp_tol(refi, 1.0):.1f} ulps), rel-L2 {rel:.2e}")
-            assert d <= _ulp_tol(refi) and rel < 3e-2
-            assert refi[int(forced.argmax())] >= refi.max() - _ulp_tol(refi)
+    for i in range(N_STEPS):
+        forced = eng.decode_forced([toks[i]])[0]
+        refi = step_logits[i]
+        d, rel = np.abs(forced - refi).max(), np.linalg.norm(forced - refi) / np.linalg.norm(refi)
+        print(f"  step {i} (ctx {406 + i}): max|d| {d:.4f} ({d / _ulp_tol(refi, 1.0):.1f} ulps), rel-L2 {rel:.2e}")
+        assert d <= _ulp_tol(refi) and rel < 3e-2
+        assert refi[int(forced.argmax())] >= refi.max() - _ulp_tol(refi)
 
 
 @pytest.mark.parametrize("nbuf", [0, 1, 2], ids=["gemm-auto", "gemm-glds1(bench form)", "gemm-double-buffered"])

@@ -78,7 +78,7 @@ def _frac_over_2ulp(a, b):
 
 
 @pytest.mark.parametrize("depth", [1, 6, 18])
-def test_encoder_flip_fraction_grows_like_a_reordered_cpu_sum(depth):
+def test_encoder_flip_fraction_grows_like_a_reordered_cpu_sum(depth, sd_small_stress):
     """Distributional bound (replaces the dropped `bad.mean() < 0.05` check of round 1, which failed at 10-18 %).
 
     Claim under test: the device differs from the DEVICE-policy oracle only because f32 sums are associated differently,
@@ -94,7 +94,7 @@ def test_encoder_flip_fraction_grows_like_a_reordered_cpu_sum(depth):
     import dataclasses
     from oracle import mel as omel
     a = dataclasses.replace(C.AUDIO_SMALL, layers=depth)
-    sd = synth.synth_state_dict(C.AUDIO_SMALL, C.TEXT_SMALL, seed=0, init="stress")
+    sd = sd_small_stress
     eng = gpu_util.Engine("0.6B", max_batch=1, max_audio_seconds=30, enc_layers=depth)
     try:
         eng.load_state_dict(sd)

@@ -27,8 +27,8 @@ def _tol(ref):
 
 
 @pytest.fixture(scope="module")
-def full():
-    sd = synth.synth_state_dict(C.AUDIO_SMALL, C.TEXT_SMALL, seed=0, init="stress")
+def full(sd_small_stress):
+    sd = sd_small_stress
     e = gpu_util.Engine("0.6B", max_batch=32, max_audio_seconds=6, max_new_tokens=32)
     e.load_state_dict(sd)
     yield e, sd
