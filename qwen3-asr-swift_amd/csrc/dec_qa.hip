@@ -41,7 +41,10 @@ __device__ __forceinline__ long qa_vfrag_index(int key, int d) {       // = vfra
 
 // ST: diagnostic instantiation (qasr_kernel_probe 7), stamps of the 100 MHz clock in a.dbg[wg * 32 + i]: thread 0: 0 entry, 1 rows staged,
 // 2 projection summed, 3 signalled, 4 wait over, 7 output stored; thread 64 (wave 1): 5 own rows AND its K / V chunks in, 6 sweep done
-template <int NB, bool ST>
+// EARLY: which waves request the K half of their first chunk before the projection: 0 none | 1 all | 2 waves 4..7 (A/B, knob qa_early).
+// GATE: 1 = waves 1..7 hold their remaining requests until wave 0 has stored, drained and signalled the projection (so that the hand-off's
+//       write-through stores are not queued behind the stream) | 0 = they request as soon as the sums are in (knob qa_gate).
+template <int NB, bool ST, int EARLY, int GATE>
 __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     constexpr int HD = QA_HD, REP = 2, KS = HD / 32, DT = HD / 16, HALF = HD / 2, WAVES = CWAVES, UNR = QA_UNR;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -103,7 +106,9 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         for (int dt = 0; dt < DT; ++dt)
             vreg[u][dt] = *reinterpret_cast<const uint4*>(has_att ? vfb + ((long)ch_early[u] * DT + dt) * 512 : kdummy);
     };
-    request_k(0);
+    // (wave 0 may take part: its 8 requests have landed long before its drain)
+    const bool early_wave = EARLY == 1 || (EARLY == 2 && wave >= 4);
+    if constexpr (EARLY != 0) { if (early_wave) request_k(0); }
     if (tid < 128) reinterpret_cast<uint4*>(dsm + L_NORM)[tid] = nw;
     __syncthreads();
 
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     {
         f32x4 acc[1][NB];
         chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1);
-        if (wave != 0) { request_v(0); request_k(1); request_v(1); }
+        auto rest = [&]() { if (!early_wave) request_k(0); request_v(0); request_k(1); request_v(1); };
+        if constexpr (!GATE) { if (wave != 0) rest(); }
         if (wave == 0) {
 #pragma unroll
             for (int p = 0; p < NB; ++p) {
@@ -130,6 +136,10 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             const int grp = wg < 128 ? wg >> 4 : (wg < 192 ? (wg - 128) >> 3 : (wg - 192) >> 3);
             seam_signal(a.ctr, 3, grp);
             QA_STAMP(3, 0);
+        }
+        if constexpr (GATE) {
+            __syncthreads();
+            if (wave != 0) rest();
         }
     }
     if (!has_att) return;
@@ -209,6 +219,13 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         }
         // the rest of wave 0's chunks (its first K half came in with everybody's)
         if (wave < nchunks) {
+            if (!early_wave) {
+                const bf16_t* kr = kb + ((long)ch_early[0] * 32 + fr) * HD;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kreg[0][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+            }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) vreg[0][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[0] * DT + dt) * 512);
         }
@@ -360,8 +377,16 @@ void decode_qa_launch(const DecQaArgs& a, hipStream_t s) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k), L_TOTAL);
         hipLaunchKernelGGL(k, dim3(256), dim3(CT), L_TOTAL, s, a);
     };
-    if (a.dbg) { if (a.B <= 16) go(decode_qa_kernel<1, true>); else go(decode_qa_kernel<2, true>); }
-    else { if (a.B <= 16) go(decode_qa_kernel<1, false>); else go(decode_qa_kernel<2, false>); }
+    const int early = tuning().qa_early, gate = tuning().qa_gate;
+#define QA_GO(E_, G_)                                                                                                   \
+    do {                                                                                                                  \
+        if (a.dbg) { if (a.B <= 16) go(decode_qa_kernel<1, true, E_, G_>); else go(decode_qa_kernel<2, true, E_, G_>); }  \
+        else { if (a.B <= 16) go(decode_qa_kernel<1, false, E_, G_>); else go(decode_qa_kernel<2, false, E_, G_>); }      \
+    } while (0)
+    if (early == 0) { if (gate) QA_GO(0, 1); else QA_GO(0, 0); }
+    else if (early == 2) { if (gate) QA_GO(2, 1); else QA_GO(2, 0); }
+    else { if (gate) QA_GO(1, 1); else QA_GO(1, 0); }
+#undef QA_GO
 }
 
 }  // namespace qasr

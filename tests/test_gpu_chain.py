@@ -25,7 +25,7 @@ def eng():
     e.set_tuning("chain", 0)
     e.set_tuning("chain_proto", 0)
     e.set_tuning("chain_pf", 0)
-    e.set_tuning("qa", 0)
+    e.set_tuning("qa", 1)
     e.close()
 
 
@@ -40,6 +40,7 @@ def test_chain_equals_five_launch_layer_bit_for_bit(eng, proto, pf):
     emb = P.bf16_round(torch.randn(33, 1024, generator=torch.Generator().manual_seed(7)) * 0.5).numpy()
     clips = [synth.synth_waveform(k, 1.0 + 0.17 * (k % 5)) for k in range(32)]
     eng.set_tuning("chain", 0)
+    eng.set_tuning("qa", 0)                                    # base = the five-launch layer
     eng.set_tuning("chain_proto", proto)
     eng.set_tuning("chain_pf", pf)
     base = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
@@ -53,7 +54,7 @@ def test_chain_equals_five_launch_layer_bit_for_bit(eng, proto, pf):
         for b, (g, w) in zip((1, 8, 16, 17, 32), zip(got[2], base[2])):
             assert g == w, (mode, qa, b)
     eng.set_tuning("chain", 0)
-    eng.set_tuning("qa", 0)
+    eng.set_tuning("qa", 1)                                    # the library's default
 
 
 def test_chain_natural_eos_and_reruns(eng):
@@ -61,14 +62,35 @@ def test_chain_natural_eos_and_reruns(eng):
     from zero; rows that finish early (natural EOS under the stress weights, or the 448-token cap) keep running through the launch."""
     clips = [synth.synth_waveform(40 + k, 0.8 + 0.1 * (k % 7)) for k in range(24)]
     eng.set_tuning("chain", 0)
+    eng.set_tuning("qa", 0)
     want = eng.transcribe_batch(clips, max_tokens=16)
-    for mode, qa in ((3, 0), (2, 1)):
+    for mode, qa in ((3, 0), (2, 1), (0, 1)):
         eng.set_tuning("chain", mode)
         eng.set_tuning("qa", qa)
         for _ in range(3):
             assert eng.transcribe_batch(clips, max_tokens=16) == want
     eng.set_tuning("chain", 0)
+    eng.set_tuning("qa", 1)
+
+
+def test_qa_request_schedules_agree(eng):
+    """The request schedules of the fused q|k|v + attention launch (knobs qa_early, qa_gate: which waves ask for the first K half before the
+    projection, whether the rest waits for the hand-off's signal) only move requests in time: same tokens as the two-launch layer."""
+    clips = [synth.synth_waveform(70 + k, 0.9 + 0.13 * (k % 6)) for k in range(32)]
+    eng.set_tuning("chain", 0)
     eng.set_tuning("qa", 0)
+    want = [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)]
+    eng.set_tuning("qa", 1)
+    try:
+        for early in (0, 1, 2):
+            for gate in (0, 1):
+                eng.set_tuning("qa_early", early)
+                eng.set_tuning("qa_gate", gate)
+                assert [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)] == want, (early, gate)
+    finally:
+        eng.set_tuning("qa_early", 1)
+        eng.set_tuning("qa_gate", 0)
+        eng.set_tuning("qa", 1)
 
 
 def test_qa_long_context_second_round():
@@ -86,5 +108,5 @@ def test_qa_long_context_second_round():
         e.set_tuning("qa", 1)
         assert e.transcribe_batch(clips, max_tokens=20, ignore_eos=True) == want
     finally:
-        e.set_tuning("qa", 0)
+        e.set_tuning("qa", 1)
         e.close()
