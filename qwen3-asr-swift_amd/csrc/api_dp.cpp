@@ -201,7 +201,10 @@ int qasr_dp_collect(qasr_dp* dp, int64_t ticket, int32_t* tokens, int32_t* lens)
         dp->last_error = "ticket " + std::to_string(ticket) + " is not in flight (already collected, or never issued)";
         return QASR_ERR_INVALID;
     }
-    if (l.B && (!tokens || !lens)) return QASR_ERR_INVALID;      // the batch stays in flight: call again with buffers
+    if (l.B && (!tokens || !lens)) {                            // the batch stays in flight: call again with buffers
+        dp->last_error = "qasr_dp_collect: ticket " + std::to_string(ticket) + " needs token and length buffers (the batch stays in flight)";
+        return QASR_ERR_INVALID;
+    }
     l.worker.join();
     l.ticket = -1;
     if (l.rc != QASR_OK) {

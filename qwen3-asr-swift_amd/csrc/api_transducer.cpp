@@ -170,11 +170,13 @@ float qasr_transducer_confidence(const float* log_probs, int32_t n) {
 // ---- vocabulary -------------------------------------------------------------------------------------------------------------
 int qasr_sp_vocab_create(const int32_t* ids, const char* const* pieces, size_t n, int style, qasr_sp_vocab** out) {
     if (!out || (style != 0 && style != 1) || (n && (!ids || !pieces))) return QASR_ERR_INVALID;
-    auto* v = new qasr_sp_vocab();
-    v->v.style = style;
-    for (size_t i = 0; i < n; ++i) v->v.table[ids[i]] = pieces[i] ? pieces[i] : "";
-    *out = v;
-    return QASR_OK;
+    try {
+        auto v = std::make_unique<qasr_sp_vocab>();
+        v->v.style = style;
+        for (size_t i = 0; i < n; ++i) v->v.table[ids[i]] = pieces[i] ? pieces[i] : "";
+        *out = v.release();
+        return QASR_OK;
+    } catch (...) { return QASR_ERR_INVALID; }          // allocation failure: nothing crosses the C boundary
 }
 int qasr_sp_vocab_load(const char* path, int style, qasr_sp_vocab** out) {
     if (!out || !path || (style != 0 && style != 1)) return QASR_ERR_INVALID;
@@ -190,34 +192,40 @@ int qasr_sp_vocab_count(const qasr_sp_vocab* v) { return v ? (int)v->v.table.siz
 
 int qasr_sp_vocab_decode(const qasr_sp_vocab* v, const int32_t* ids, int32_t n, char* buf, size_t cap) {
     if (!v || (!ids && n) || n < 0 || !buf || cap == 0) return -1;
-    const std::string t = v->v.decode(ids, n);
-    if (t.size() + 1 > cap) return -1;
-    std::memcpy(buf, t.c_str(), t.size() + 1);
-    return (int)t.size();
+    try {
+        const std::string t = v->v.decode(ids, n);
+        if (t.size() + 1 > cap) return -1;
+        std::memcpy(buf, t.c_str(), t.size() + 1);
+        return (int)t.size();
+    } catch (...) { return -1; }
 }
 
 int qasr_sp_vocab_decode_words(const qasr_sp_vocab* v, const int32_t* ids, int32_t n_ids, const float* log_probs, int32_t n_lp, char* buf,
                                size_t cap, float* confidences, int32_t conf_cap) {
     if (!v || (!ids && n_ids) || (!log_probs && n_lp) || n_ids < 0 || n_lp < 0 || !buf || cap == 0 || conf_cap < 0 || (!confidences && conf_cap)) return -1;
-    std::vector<std::string> words;
-    std::vector<float> conf;
-    v->v.decode_words(ids, n_ids, log_probs, n_lp, words, conf);
-    std::string joined;
-    for (size_t i = 0; i < words.size(); ++i) { if (i) joined += '\n'; joined += words[i]; }
-    if (joined.size() + 1 > cap || (int64_t)words.size() > conf_cap) return -1;
-    std::memcpy(buf, joined.c_str(), joined.size() + 1);
-    for (size_t i = 0; i < conf.size(); ++i) confidences[i] = conf[i];
-    return (int)words.size();
+    try {
+        std::vector<std::string> words;
+        std::vector<float> conf;
+        v->v.decode_words(ids, n_ids, log_probs, n_lp, words, conf);
+        std::string joined;
+        for (size_t i = 0; i < words.size(); ++i) { if (i) joined += '\n'; joined += words[i]; }
+        if (joined.size() + 1 > cap || (int64_t)words.size() > conf_cap) return -1;
+        std::memcpy(buf, joined.c_str(), joined.size() + 1);
+        for (size_t i = 0; i < conf.size(); ++i) confidences[i] = conf[i];
+        return (int)words.size();
+    } catch (...) { return -1; }
 }
 
 // ---- chunk cutting ----------------------------------------------------------------------------------------------------------
 int qasr_stream_chunker_create(int32_t samples_per_chunk, int32_t shift, qasr_stream_chunker** out) {
     if (!out || samples_per_chunk <= 0 || shift <= 0 || shift > samples_per_chunk) return QASR_ERR_INVALID;
-    auto* c = new qasr_stream_chunker();
-    c->c.samples_per_chunk = samples_per_chunk;
-    c->c.shift = shift;
-    *out = c;
-    return QASR_OK;
+    try {
+        auto c = std::make_unique<qasr_stream_chunker>();
+        c->c.samples_per_chunk = samples_per_chunk;
+        c->c.shift = shift;
+        *out = c.release();
+        return QASR_OK;
+    } catch (...) { return QASR_ERR_INVALID; }
 }
 void qasr_stream_chunker_destroy(qasr_stream_chunker* c) { delete c; }
 int qasr_stream_chunker_push(qasr_stream_chunker* c, const float* samples, size_t n) {

@@ -443,7 +443,7 @@ static bool gemv2_k(const DecGemv2Args& a2, hipStream_t s) {
 
 // Fused form used by the decode step: optional RMSNorm prologue (norm_w != null) + epilogue.
 // Falls back to [rmsnorm_rows +] the generic kernel for shapes without a tuned instantiation.
-static unsigned long long* g_gemv_dbg = nullptr;
+static thread_local unsigned long long* g_gemv_dbg = nullptr;      // per host thread: engines of several devices step concurrently (qasr_dp_*)
 void decode_gemv_set_debug(unsigned long long* dbg) { g_gemv_dbg = dbg; }
 int decode_gemv_fused_launch(DecEpi epi, const DecGemvArgs& a, const bf16_t* norm_w, float eps, bf16_t* norm_scratch,
                              hipStream_t s) {

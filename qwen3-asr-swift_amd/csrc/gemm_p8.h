@@ -292,13 +292,21 @@ inline bool gemm_use_p8(int M, int N) {
 
 // persistent grid: one workgroup per CU (128 KiB of LDS each), fewer when the launch has fewer tiles
 inline int gemm_p8_grid(int M, int N) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        QASR_HIP(hipGetDevice(&dev));
-        QASR_HIP(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // CU count of the CALLING thread's device, cached per device under a lock: one process may drive an engine per GPU from several threads
+    static std::mutex mu;
+    static int cus_of[64] = {0};
+    int dev = 0;
+    QASR_HIP(hipGetDevice(&dev));
+    int cus;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 64) throw std::invalid_argument("gemm_p8_grid: device ordinal out of range");
+        if (!cus_of[dev]) {
+            hipDeviceProp_t prop;
+            QASR_HIP(hipGetDeviceProperties(&prop, dev));
+            cus_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        cus = cus_of[dev];
     }
     const long tiles = (long)cdiv(M, P8_BM) * cdiv(N, P8_BN);
     return (int)(tiles < cus ? tiles : cus);

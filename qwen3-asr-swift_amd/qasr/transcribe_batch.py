@@ -54,7 +54,7 @@ def run(model, files, batch=1, language=None, output_dir=None, jsonl=False, out=
     texts = {}
     batch_start = time.perf_counter()
     lang_ids = model.encode_text("language " + language) if language else None
-    state = {"tick": batch_start}
+    state = {"tick": batch_start, "io": 0.0}
     pending = []                       # lanes: (ticket, group, clips, names, errors) of the passes in flight, oldest first
 
     def report(group, clips, names, errors, toks, elapsed):
@@ -89,14 +89,17 @@ def run(model, files, batch=1, language=None, output_dir=None, jsonl=False, out=
         ticket, group, clips, names, errors = pending.pop(0)
         toks = lanes.collect(ticket) if ticket is not None else []
         now = time.perf_counter()
-        # passes overlap on the GPU: a group is charged the time since the previous group finished, so the charges add up to the wall
-        # time of the whole job and Aggregate RTF stays sum(charged) / sum(audio)
-        report(group, clips, names, errors, toks, now - state["tick"])
+        # passes overlap on the GPU: a group is charged the time since the previous group finished MINUS the file reading done in that
+        # interval (the reference's per-file timer starts after the load, TranscribeBatchCommand.swift:91-94), so the charges add up to the
+        # inference wall time of the whole job and Aggregate RTF stays sum(charged) / sum(audio)
+        report(group, clips, names, errors, toks, max(now - state["tick"] - state["io"], 0.0))
         state["tick"] = now
+        state["io"] = 0.0
 
     for b0 in range(0, len(files), batch):
         group = files[b0:b0 + batch]
         clips, names, errors = [], [], {}
+        t_io = time.perf_counter()
         for path in group:
             name = os.path.splitext(os.path.basename(path))[0]
             try:
@@ -110,6 +113,7 @@ def run(model, files, batch=1, language=None, output_dir=None, jsonl=False, out=
             except Exception as ex:      # noqa: BLE001 -- per-file errors are reported and the batch goes on (:121-127)
                 errors[name] = str(ex)
         if lanes is not None:
+            state["io"] += time.perf_counter() - t_io
             if len(pending) == lanes.n_devices:
                 collect_oldest()
             ticket = lanes.submit(clips, max_tokens=max_tokens, language_ids=lang_ids) if clips else None
