@@ -57,11 +57,11 @@ def test_encoder_tiny(tiny, T):
     _check(got, sd, mel, C.AUDIO_TINY, exact=T <= 16)
 
 
-def test_encoder_full_size_5s():
+def test_encoder_full_size_5s(sd_small_stress):
     """Qwen3-ASR-0.6B geometry (d=896, 18 layers, 480 conv channels), 5 s clip = configs[0] shape."""
     from oracle import mel as omel
     a = C.AUDIO_SMALL
-    full = synth.synth_state_dict(a, C.TEXT_SMALL, seed=0, init="stress")
+    full = sd_small_stress
     eng = gpu_util.Engine("0.6B", max_batch=1, max_audio_seconds=6)
     try:
         eng.load_state_dict(full)
