@@ -67,6 +67,9 @@ struct AGroupConv1d {
         const bf16_t* p = addr(r, k);
         return p ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
     }
+    struct KT { int k; };                                                  // K-tile form of addr (gemm.h)
+    __device__ __forceinline__ KT ktile(int k0, int c8) const { return {k0 + c8}; }
+    __device__ __forceinline__ const bf16_t* addr_kt(const Row& r, const KT& t) const { return addr(r, t.k); }
 };
 
 // ---- epilogues with f32 parameters ------------------------------------------------------------------

@@ -238,12 +238,15 @@ void Engine::run_encoder() {
     {
         AConv3x3s2 a{c1, H1_, W1_, C, H2_, W2_, n_img_ * H2_ * W2_, K9, true};
         EpiConvGelu e{c2, C, encw_.c2b, d_chunks_, H2_, W2_, true, 2};
-        gemm_nt(a, encw_.c2w, K9, a.M, C, K9, e, s);
+        // C >= 64: a K-tile touches at most two taps -> the functor with the per-K-tile scalar decomposition (gemm.h AConv3x3s2W, same bits)
+        if (C >= GEMM_BK && tuning().conv_ktile) gemm_nt(AConv3x3s2W{a}, encw_.c2w, K9, a.M, C, K9, e, s);
+        else gemm_nt(a, encw_.c2w, K9, a.M, C, K9, e, s);
     }
     {
         AConv3x3s2 a{c2, H2_, W2_, C, H3_, W3_, n_img_ * H3_ * W3_, K9, false};
         EpiConvGelu e{c3, C, encw_.c3b, d_chunks_, H3_, W3_, false, 3};
-        gemm_nt(a, encw_.c3w, K9, a.M, C, K9, e, s);
+        if (C >= GEMM_BK && tuning().conv_ktile) gemm_nt(AConv3x3s2W{a}, encw_.c3w, K9, a.M, C, K9, e, s);
+        else gemm_nt(a, encw_.c3w, K9, a.M, C, K9, e, s);
     }
     {
         ARowTable a{c3, d_tok_rowoff_, n_tok_, H3_ * C};

@@ -31,6 +31,10 @@ struct ADense {
         return make_uint4(0, 0, 0, 0);
     }
     __device__ __forceinline__ const bf16_t* addr(const Row& r, int k) const { return (r.p && k < K) ? r.p + k : nullptr; }
+    // K-tile form of addr: ktile(k0, c8) once per staged K-tile (k0 wave-uniform, c8 this lane's chunk offset), addr_kt per row
+    struct KT { int k; };
+    __device__ __forceinline__ KT ktile(int k0, int c8) const { return {k0 + c8}; }
+    __device__ __forceinline__ const bf16_t* addr_kt(const Row& r, const KT& t) const { return addr(r, t.k); }
 };
 
 // rows addressed through an element-offset table (packed valid tokens -> conv3 output rows)
@@ -45,6 +49,10 @@ struct ARowTable {
         return make_uint4(0, 0, 0, 0);
     }
     __device__ __forceinline__ const bf16_t* addr(const Row& r, int k) const { return (r.p && k < K) ? r.p + k : nullptr; }
+    // K-tile form of addr: ktile(k0, c8) once per staged K-tile (k0 wave-uniform, c8 this lane's chunk offset), addr_kt per row
+    struct KT { int k; };
+    __device__ __forceinline__ KT ktile(int k0, int c8) const { return {k0 + c8}; }
+    __device__ __forceinline__ const bf16_t* addr_kt(const Row& r, const KT& t) const { return addr(r, t.k); }
 };
 
 // Implicit GEMM for a 3x3 / stride 2 / pad 1 convolution over NHWC bf16 input [img][H][W][C].
@@ -86,6 +94,31 @@ struct AConv3x3s2 {
         if (!((r.mask >> tap) & 1u)) return nullptr;
         int kh = tap / 3, kw = tap - kh * 3;
         return r.base + ((long)kh * W + kw) * C + ci;
+    }
+    struct KT { int k; };
+    __device__ __forceinline__ KT ktile(int k0, int c8) const { return {k0 + c8}; }
+    __device__ __forceinline__ const bf16_t* addr_kt(const Row& r, const KT& t) const { return addr(r, t.k); }
+};
+
+// The same gather for C >= 64 (every real geometry: 480) with the K-tile's tap decomposed ONCE per staged K-tile on the scalar unit: a
+// 64-wide K-tile starts inside tap0 and ends inside tap0 or tap0 + 1, so a lane only adds its chunk offset, tests one wrap and selects one of
+// two tap offsets -- the per-chunk division, tap / 3 and multiplies of addr() sat on the critical path of the implicit-conv launches (a dense
+// GEMM of the same shape ran 18 % faster, round 1; adding one more select to addr() cost the encoder 3 ms, profiles/r04_ab_conv_korder.txt).
+// Same k order, same values: bit-identical to AConv3x3s2.
+struct AConv3x3s2W : AConv3x3s2 {
+    struct KT { int off; int tap; bool in_k; };
+    __device__ __forceinline__ KT ktile(int k0, int c8) const {
+        const unsigned k0u = (unsigned)__builtin_amdgcn_readfirstlane(k0);
+        const int tap0 = (int)__umulhi(k0u, (0xffffffffu / (unsigned)C) + 1u), ci0 = (int)k0u - tap0 * C;      // scalar
+        const int tap1 = tap0 + 1;
+        const int off0 = (((tap0 * 11) >> 5) * W + (tap0 - 3 * ((tap0 * 11) >> 5))) * C;                        // (kh * W + kw) * C, tap < 10
+        const int off1 = (((tap1 * 11) >> 5) * W + (tap1 - 3 * ((tap1 * 11) >> 5))) * C;
+        const int c = ci0 + c8;
+        const bool wrap = c >= C;
+        return {(wrap ? off1 - C : off0) + c, wrap ? tap1 : tap0, (int)k0u + c8 < K};
+    }
+    __device__ __forceinline__ const bf16_t* addr_kt(const Row& r, const KT& t) const {
+        return (t.in_k && ((r.mask >> t.tap) & 1u)) ? r.base + t.off : nullptr;
     }
 };
 
@@ -165,9 +198,10 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
     }
     auto stage = [&](int buf, int kt) {
         const int k = kt * GEMM_BK + schunk * 8;
+        const typename ALoad::KT akt = aload.ktile(kt * GEMM_BK, schunk * 8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bf16_t* pa = aload.addr(arow[i], k);
+            const bf16_t* pa = aload.addr_kt(arow[i], akt);
             const bf16_t* pb = (wrow[i] && k < K) ? wrow[i] + k : nullptr;
             const int off = (wave * 4 + i) * 1024;      // wave-uniform LDS base of this instruction
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa ? pa : zeros), (lds_ptr_t)&smem[(buf * 2 + 0) * OPB + off], 16, 0, 0);

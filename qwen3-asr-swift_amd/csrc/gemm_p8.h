@@ -77,10 +77,10 @@ __global__ __launch_bounds__(P8_THREADS) void gemm_nt_p8_kernel(ALoad aload, con
         }
     };
     auto stage_a = [&](int unit, int kt, const typename ALoad::Row* rows) {
-        const int k = kt * GEMM_BK + schunk * 8;
+        const typename ALoad::KT akt = aload.ktile(kt * GEMM_BK, schunk * 8);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bf16_t* p = aload.addr(rows[i], k);
+            const bf16_t* p = aload.addr_kt(rows[i], akt);
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(p ? p : zeros), (lds_ptr_t)&smem[((kt & 1) * 4 + unit) * P8_UNIT + (wave * 2 + i) * 1024], 16, 0, 0);
         }
     };

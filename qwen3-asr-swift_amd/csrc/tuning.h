@@ -34,6 +34,7 @@ struct Tuning {
     int pa_order = 1;        // prompt attention workgroup order: 1 longest query tiles first, kv head = XCD | 0 query tile fastest
     int pa_mt = 1;           // row tiles per wave of the first form
     int qknr_wide = 1;       // q/k norm + RoPE of the prompt pass: 16-byte accesses
+    int conv_ktile = 1;      // implicit-GEMM convolutions (C >= 64): tap decomposition once per staged K-tile on the scalar unit (AConv3x3s2W) | 0 per chunk
     int enc_attn = 1;        // Qwen3 audio-encoder window attention at head_dim 64: 1 the wav2vec2 path's 32x32x16 kernel | 0 16-row kernel
     int mha_form = 1;        // Omnilingual attention at head_dim 64: 1 | 2 transposed scores on 32x32x16 MFMAs, 128 | 256 queries per workgroup; 0 16x16x32 form
     int gemm_p8 = 1;         // 256 x 256 ping-pong GEMM form: 0 never | 1 for launches of many tiles | 2 always

@@ -69,7 +69,12 @@ def test_encoder_full_size_5s(sd_small_stress):
         got = eng.encode(mel)
         assert got.shape == (65, 1024)
         _check(got, full, mel, a)
+        # the implicit-GEMM convolutions decompose a K-tile's tap once per tile on the scalar unit (gemm.h AConv3x3s2W, default) or per
+        # 16-byte chunk (AConv3x3s2): same addresses, same k order -> same bits
+        eng.set_tuning("conv_ktile", 0)
+        assert np.array_equal(eng.encode(mel), got)
     finally:
+        eng.set_tuning("conv_ktile", 1)
         eng.close()
 
 
