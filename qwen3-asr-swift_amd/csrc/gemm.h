@@ -170,7 +170,7 @@ struct epi_pre_type<E, true> { using type = typename E::Pre; };
 template <class ALoad, class Epi, int MODE, int NBUF>
 __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBUF][A|B][128 rows x 128 B] */, const ALoad& aload,
                                                  const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, const Epi& epi,
-                                                 const bf16_t* __restrict__ zeros) {
+                                                 const bf16_t* __restrict__ zeros, int tm = 1) {
     constexpr int OPB = GEMM_BM * 128;                  // bytes of one operand image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -182,7 +182,20 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = (bid / nbx) * GEMM_BM, n0 = (bid % nbx) * GEMM_BN;
+    // tm > 1: the tile list runs in blocks of tm row panels, column tile by column tile inside a block, panel fastest (like gemm_p8.h): the
+    // ~128 tiles an XCD has in flight then span tm row panels x 128 / tm column tiles instead of 128 / nbx panels x all nbx columns -- fewer
+    // distinct operand bytes behind them (the q|k|v GEMM of the prompt pass fetched 484 MB for 35 MB of operands, profiles/r04_v1_pmc_per_kernel.csv)
+    int m0, n0;
+    if (tm > 1) {
+        const int nby = (M + GEMM_BM - 1) / GEMM_BM;
+        const int blk = bid / (tm * nbx), i = bid - blk * (tm * nbx);
+        const int rows_in_blk = nby - blk * tm < tm ? nby - blk * tm : tm;
+        m0 = (blk * tm + i % rows_in_blk) * GEMM_BM;
+        n0 = (i / rows_in_blk) * GEMM_BN;
+    } else {
+        m0 = (bid / nbx) * GEMM_BM;
+        n0 = (bid % nbx) * GEMM_BN;
+    }
 
     // staging: wave w, instruction i covers tile rows (w*4 + i)*8 .. +7; lane -> (row + lane/8, LDS slot lane%8)
     const int srow = lane >> 3;
@@ -303,16 +316,16 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
 
 template <class ALoad, class Epi, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_glds_kernel(ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N,
-                                                                     int K, Epi epi, const bf16_t* __restrict__ zeros) {
+                                                                     int K, Epi epi, const bf16_t* __restrict__ zeros, int tm) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * GEMM_BM * 128];
-    gemm_nt_128_body<ALoad, Epi, MODE, 2>(smem, aload, Wt, ldw, M, N, K, epi, zeros);
+    gemm_nt_128_body<ALoad, Epi, MODE, 2>(smem, aload, Wt, ldw, M, N, K, epi, zeros, tm);
 }
 
 template <class ALoad, class Epi, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_glds1_kernel(
-    ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, Epi epi, const bf16_t* __restrict__ zeros) {
+    ALoad aload, const bf16_t* __restrict__ Wt, long ldw, int M, int N, int K, Epi epi, const bf16_t* __restrict__ zeros, int tm) {
     __shared__ __attribute__((aligned(1024))) char smem[1 * 2 * GEMM_BM * 128];
-    gemm_nt_128_body<ALoad, Epi, MODE, 1>(smem, aload, Wt, ldw, M, N, K, epi, zeros);
+    gemm_nt_128_body<ALoad, Epi, MODE, 1>(smem, aload, Wt, ldw, M, N, K, epi, zeros, tm);
 }
 
 // Grouped form: gridDim.y independent GEMMs of one shape in ONE launch (the 16 groups of the wav2vec2 positional conv: each is
@@ -362,6 +375,14 @@ struct gemm_p8_allowed { static constexpr bool value = true; };
 template <class A>
 struct gemm_p8_allowed<A, std::void_t<decltype(A::no_p8)>> { static constexpr bool value = !A::no_p8; };
 
+// row panels per block of the 128 x 128 forms' tile order (gemm_nt_128_body): knob gemm_tm, 1 = row-panel-major (rounds 1-3); only where the
+// launch has several blocks of that height and more column tiles than an XCD's share of a block
+inline int gemm_tile_rows(int M, int N) {
+    const int tm = tuning().gemm_tm;
+    const int nby = cdiv(M, GEMM_BM), nbx = cdiv(N, GEMM_BN);
+    return (tm > 1 && nby >= 2 * tm && nbx > 128 / tm) ? tm : 1;
+}
+
 template <class ALoad, class Epi>
 // form: -1 = the engine's pick for this shape (tuning knobs gemm_p8 / gemm_nbuf); 0 = 128x128 double-buffered, 1 = 128x128 single LDS
 // buffer, 2 = 256x256 ping-pong -- forced by qasr_gemm_probe without touching the process-wide knob table
@@ -375,10 +396,10 @@ inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, in
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
     if (form == 1 || (form != 0 && gemm_nbuf(grid) == 1))
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
-                           gemm_zero_block());
+                           gemm_zero_block(), gemm_tile_rows(M, N));
     else
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
-                           gemm_zero_block());
+                           gemm_zero_block(), gemm_tile_rows(M, N));
 }
 
 template <class ALoad, class Epi>
@@ -402,10 +423,10 @@ inline void gemm_nt_swiglu(const ALoad& a, const bf16_t* Wt, long ldw, int M, in
     int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
     if (gemm_nbuf(grid) == 1)
         hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
-                           gemm_zero_block());
+                           gemm_zero_block(), gemm_tile_rows(M, N));
     else
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 1>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
-                           gemm_zero_block());
+                           gemm_zero_block(), gemm_tile_rows(M, N));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ struct Tuning {
     int enc_attn = 1;        // Qwen3 audio-encoder window attention at head_dim 64: 1 the wav2vec2 path's 32x32x16 kernel | 0 16-row kernel
     int mha_form = 1;        // Omnilingual attention at head_dim 64: 1 | 2 transposed scores on 32x32x16 MFMAs, 128 | 256 queries per workgroup; 0 16x16x32 form
     int gemm_p8 = 1;         // 256 x 256 ping-pong GEMM form: 0 never | 1 for launches of many tiles | 2 always
+    int gemm_tm = 8;         // 128 x 128 GEMM forms: tile order in blocks of this many row panels (1 = row-panel-major) -- A/B in profiles/r04_ab_gemm_order.txt
     int gemm_nbuf = 0;       // GEMM LDS buffers: 0 auto (by tile count) | 1 | 2
     int lmh_q_ring = 1;      // quantised LM head weight stream: 1 wave-private LDS ring (direct-to-LDS) | 0 register ring of four blocks
     int lmh_grid = 256;      // persistent LM-head workgroups (read at qasr_finalize: sizes the argmax partials)
