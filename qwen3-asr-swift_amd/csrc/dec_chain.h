@@ -53,6 +53,7 @@ struct DecQaArgs {
     unsigned epoch;         // layer index
     int* err;
     unsigned long long* dbg = nullptr;   // diagnostic: [256][32] phase stamps (qasr_kernel_probe 7), null in product launches
+    int fault = 0;          // test only (knob chain_fault): workgroup 5 never signals -> the bounded waits must end the step with CHAIN_ERR_TIMEOUT
 };
 bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_ctx);
 void decode_qa_launch(const DecQaArgs& a, hipStream_t s);

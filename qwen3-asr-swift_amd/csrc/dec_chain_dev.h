@@ -58,13 +58,17 @@ __device__ __forceinline__ void seam_signal(unsigned* ctr, int seam, int unit) {
 // up (uniform over the workgroup)
 __device__ __forceinline__ bool seam_wait_n(const unsigned* c0, int nshards, unsigned target, int* err, int* s_flag) {
     if (threadIdx.x < 64) {
-        const unsigned* c = c0 + (threadIdx.x & (CHAIN_SHARDS - 1)) * CHAIN_SHARD_WORDS;
+        // lanes 0 .. nshards - 1 poll the counters; lane 63 polls the error word in the same instruction: once ANY wait of the step has given
+        // up, every later wait fails at its first poll (a step that lost one arrival would otherwise spend the budget in each of its launches)
+        const bool on_ctr = (int)threadIdx.x < nshards, on_err = threadIdx.x == 63;
+        const unsigned* c = on_err ? reinterpret_cast<const unsigned*>(err) : c0 + (threadIdx.x & (CHAIN_SHARDS - 1)) * CHAIN_SHARD_WORDS;
         const unsigned long long t0 = wall_clock64();
         bool ok;
         for (;;) {
-            const unsigned v = (int)threadIdx.x < nshards ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-            ok = __builtin_amdgcn_ballot_w64(v < target) == 0;
-            if (ok || wall_clock64() - t0 > CH_SPIN_TICKS) break;
+            const unsigned v = (on_ctr || on_err) ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const bool dead = __builtin_amdgcn_ballot_w64(on_err && (v & CHAIN_ERR_TIMEOUT)) != 0;
+            ok = !dead && __builtin_amdgcn_ballot_w64(on_ctr && v < target) == 0;
+            if (ok || dead || wall_clock64() - t0 > CH_SPIN_TICKS) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (threadIdx.x == 0) {

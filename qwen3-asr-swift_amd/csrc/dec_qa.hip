@@ -134,7 +134,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             }
             // tile -> kv head it feeds: q columns (tiles 0..127, 16 per kv head), then k (8 per head), then v
             const int grp = wg < 128 ? wg >> 4 : (wg < 192 ? (wg - 128) >> 3 : (wg - 192) >> 3);
-            seam_signal(a.ctr, 3, grp);
+            if (!(a.fault && wg == 5)) seam_signal(a.ctr, 3, grp);
             QA_STAMP(3, 0);
         }
         if constexpr (GATE) {
@@ -370,7 +370,9 @@ bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_
            cus[dev] >= 256;
 }
 
-void decode_qa_launch(const DecQaArgs& a, hipStream_t s) {
+void decode_qa_launch(const DecQaArgs& a0, hipStream_t s) {
+    DecQaArgs a = a0;
+    a.fault = tuning().chain_fault;
     if (a.B < 1 || a.B > 32) throw std::invalid_argument("decode qa: 1..32 batch rows");
     if (!a.cache.vf || a.cache.max_ctx % 32) throw std::invalid_argument("decode qa: fragment-major V image / capacity");
     auto go = [&](auto k) {

@@ -21,6 +21,8 @@ struct Tuning {
     int qa = 1;              // q|k|v projection + decode attention of a layer as one launch, K / V requested before the projection (dec_qa.hip): 1 | 0 two launches
     int qa_early = 1;        // dec_qa: waves that request the K half of their first chunk before the projection: 0 none | 1 all | 2 waves 4..7
     int qa_gate = 0;         // dec_qa: 1 waves 1..7 hold their remaining K / V requests until wave 0 has signalled the projection | 0 as soon as the sums are in
+    int chain_fault = 0;     // TEST ONLY: 1 = one workgroup of the fused q|k|v + attention launch never signals, so the bounded waits give up and the step
+                             // ends with QASR_ERR_HIP (tests/test_gpu_chain.py::test_lost_arrival_ends_in_an_error_not_a_hang)
     int chain_proto = 0;     // chain arrival counters: 0 sharded (add to one of 8, poll all 8) | 1 replicated (add to all 8, poll one)
     int chain_pf = 0;        // chain weight requests: 0 every phase's tiles at kernel entry | 1 staged (first phase first)
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)

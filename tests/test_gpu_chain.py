@@ -93,6 +93,26 @@ def test_qa_request_schedules_agree(eng):
         eng.set_tuning("qa", 1)
 
 
+def test_lost_arrival_ends_in_an_error_not_a_hang(eng):
+    """Every in-launch wait is bounded by a wall-clock budget (200 ms): with one workgroup's arrival withheld (test knob chain_fault) the
+    waiting workgroups give up, the step's later waits fail at their first poll, qasr_batch_tokens reports QASR_ERR_HIP with a message --
+    in well under the time a hang would take -- and the engine serves the next batch normally."""
+    import time
+    clips = [synth.synth_waveform(90 + k, 1.0) for k in range(32)]
+    eng.set_tuning("chain", 0)
+    eng.set_tuning("qa", 1)
+    want = eng.transcribe_batch(clips, max_tokens=6, ignore_eos=True)
+    eng.set_tuning("chain_fault", 1)
+    try:
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="hand-off wait gave up"):
+            eng.transcribe_batch(clips, max_tokens=6, ignore_eos=True)
+        assert time.perf_counter() - t0 < 5.0
+    finally:
+        eng.set_tuning("chain_fault", 0)
+    assert eng.transcribe_batch(clips, max_tokens=6, ignore_eos=True) == want
+
+
 def test_qa_long_context_second_round():
     """q|k|v + attention in one launch (csrc/dec_qa.hip): a context beyond the 512 keys that the first round of requests covers (16 chunks
     of 32 keys over 8 waves) takes further rounds inside the sweep, wave 0 requests its chunks only after the hand-off: a 41 s clip
