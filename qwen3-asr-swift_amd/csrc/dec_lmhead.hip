@@ -26,6 +26,7 @@ struct LmHeadArgs {
     float* part_val;        // [B][gridDim.x]
     int* part_idx;
     int diag;               // 1: diagnostic build of the loop without LDS reads / MFMA (wrong results, timing only)
+    int wg_fastest;         // tile -> wave order (knob lmh_order): 1 workgroup fastest | 0 wave fastest (rounds 1-3)
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned lmh_u32x4;
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
     char* s_x = dsm;
     // ---- weights of the first chunk go in flight before the activation staging -------------------------
-    const int total_waves = gridDim.x * LMH_WAVES, gw = blockIdx.x * LMH_WAVES + wave;
+    // wave index over the grid with the WORKGROUP fastest: the ntiles % total_waves waves that own one tile more are then spread over all
+    // workgroups (5 or 6 per workgroup at vocab 151 936) instead of filling the first 163 of 256 -- which streamed 40 tiles each against 32
+    const int total_waves = gridDim.x * LMH_WAVES, gw = a.wg_fastest ? wave * gridDim.x + blockIdx.x : blockIdx.x * LMH_WAVES + wave;
     const int ntiles = a.N / 16;
     const int my_tiles = gw < ntiles ? (ntiles - gw + total_waves - 1) / total_waves : 0;
     const int nitems = my_tiles * NC;
@@ -199,7 +202,7 @@ int lm_head_launch(const bf16_t* W, const bf16_t* Wp, const bf16_t* X, const bf1
     const int nb = (B + 15) / 16;
     if (Wp && lm_head_supported(N, K) && nb <= (K == 1024 ? 4 : 2)) {
         const int diag = tuning().lmh_diag;
-        LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx, diag};
+        LmHeadArgs a{Wp, X, norm_w, eps, B, N, logits, part_val, part_idx, diag, tuning().lmh_order};
         if (K == 1024) {
             switch (nb) {
                 case 1: lm_head_go<1024, 1>(a, s); break;

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
     char* s_x = dsm;                                                            // [NB*16][XSTRIDE]
     float* s_xs = reinterpret_cast<float*>(dsm + (size_t)NB * 16 * XSTRIDE);     // [G][NB*16]
     char* ring = dsm + XBYTES + (size_t)wave * (LR + SBB) * 1024;                // LR slots, then the current tile's scale / bias image
-    const int total_waves = gridDim.x * LMQ_WAVES, gw = blockIdx.x * LMQ_WAVES + wave;
+    const int total_waves = gridDim.x * LMQ_WAVES, gw = wave * gridDim.x + blockIdx.x;     // workgroup fastest: see lm_head_kernel
     const int ntiles = a.N / 16;
     const int my_tiles = gw < ntiles ? (ntiles - gw + total_waves - 1) / total_waves : 0;
     const int nblocks = my_tiles * NBLK;

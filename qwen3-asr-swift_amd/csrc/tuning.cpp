@@ -23,7 +23,7 @@ const Entry kEntries[] = {
     {"qknr_wide", &Tuning::qknr_wide, {0, 1, -1}, false},
     {"conv_ktile", &Tuning::conv_ktile, {0, 1, -1}, false}, {"enc_attn", &Tuning::enc_attn, {0, 1, -1}, false}, {"mha_form", &Tuning::mha_form, {0, 1, 2, -1}, false},
     {"gemm_p8", &Tuning::gemm_p8, {0, 1, 2, -1}, false}, {"gemm_nbuf", &Tuning::gemm_nbuf, {0, 1, 2, -1}, false}, {"gemm_tm", &Tuning::gemm_tm, {1, 4, 8, 16, -1}, false},
-    {"lmh_q_ring", &Tuning::lmh_q_ring, {0, 1, -1}, false}, {"lmh_grid", &Tuning::lmh_grid, {1, 4096, -2}, false},
+    {"lmh_q_ring", &Tuning::lmh_q_ring, {0, 1, -1}, false}, {"lmh_grid", &Tuning::lmh_grid, {1, 4096, -2}, false}, {"lmh_order", &Tuning::lmh_order, {0, 1, -1}, false},
     {"lmh_diag", &Tuning::lmh_diag, {0, 1, -1}, true},
     {"decode_split", &Tuning::decode_split, {1, 4, -2}, false}, {"decode_gran", &Tuning::decode_gran, {16, 32, 48, 64, -1}, false},
     {"graph_steps", &Tuning::graph_steps, {1, 2, 4, 8, -1}, false}, {"use_graph", &Tuning::use_graph, {0, 1, -1}, false},

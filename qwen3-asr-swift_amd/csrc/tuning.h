@@ -43,6 +43,7 @@ struct Tuning {
     int gemm_tm = 8;         // 128 x 128 GEMM forms: tile order in blocks of this many row panels (1 = row-panel-major) -- A/B in profiles/r04_ab_gemm_order.txt
     int gemm_nbuf = 0;       // GEMM LDS buffers: 0 auto (by tile count) | 1 | 2
     int lmh_q_ring = 1;      // quantised LM head weight stream: 1 wave-private LDS ring (direct-to-LDS) | 0 register ring of four blocks
+    int lmh_order = 1;       // LM head tile -> wave order: 1 workgroup fastest (the waves that own one tile more are spread over all workgroups) | 0 wave fastest
     int lmh_grid = 256;      // persistent LM-head workgroups (read at qasr_finalize: sizes the argmax partials)
     int lmh_diag = 0;        // diagnostic: LM-head loop without LDS reads / MFMA (wrong results, timing only)
     int decode_split = 1;    // decode row groups on parallel graph branches
