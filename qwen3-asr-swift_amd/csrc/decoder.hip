@@ -294,6 +294,8 @@ void Engine::finalize_decoder() {
     gstate_.max_new = cfg_.max_new_tokens;
     gstate_.eos = cfg_.tok_im_end;
     gstate_.vocab = cfg_.vocab;
+    gstate_.clear = d_chain_ctr_.as<unsigned>();
+    gstate_.clear_words = (int)(CHAIN_CTR_BYTES / sizeof(unsigned));
     for (auto& e : ev_)
         if (!e) QASR_HIP(hipEventCreate(&e));
     QASR_HIP(hipStreamSynchronize(stream_));
@@ -592,7 +594,9 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     // the whole batch in one row group (the arrival counters belong to one step of one engine), up to 32 rows
     const int chain = step_chain(r0, nr);
     const bool qa = step_qa(r0, nr, chain);
-    if (chain || qa) decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
+    // the fused launches' arrival counters start every step at zero: a greedy step is always preceded by a finalize launch (the previous step's,
+    // or the one behind the prompt pass), which zeroes them; every other caller of a step (logits for the host, forced tokens, probes) zeroes here
+    if ((chain || qa) && !(greedy && with_head)) decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
     for (int l = 0; l < cfg_.dec_layers; ++l) {
         const DecLayerW& L = decw_.layers[l];
         KVLayout kv{kcache_[l]->as<bf16_t>(), nullptr, max_ctx_, cfg_.kv_heads, hd, vfcache_[l]->as<bf16_t>()};
