@@ -6,6 +6,7 @@
 #pragma once
 #include "common.h"
 #include "gemm.h"
+#include "dec_rope.h"
 
 namespace qasr {
 
@@ -48,7 +49,9 @@ struct KVLayout {          // one layer's cache, bf16, per (slot, kv head) a blo
 void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads,
                          int hd, const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
                          const float* rope_sin, bf16_t* qr, KVLayout cache, bf16_t* vt, int vt_stride,
-                         const int* cu, const int* slot_of_clip, int n_clips, int max_len, hipStream_t s);
+                         const int* cu, const int* slot_of_clip, int n_clips, int max_len, hipStream_t s, bool v_only = false);
+// true when the q|k|v projection may run as a head-tile GEMM with EpiQkHeads (then qk_norm_rope_launch(..., v_only = true) writes the V images)
+bool qk_norm_rope_fusable(int heads, int kv_heads, int hd);
 
 // Causal flash attention over packed prompts.  clip c occupies packed rows [cu[c], cu[c+1]).
 // Online softmax in key tiles of 64 with unnormalised P rounded to bf16 (restated in
@@ -130,6 +133,75 @@ struct RopeRows {
 void greedy_finalize_launch(const float* part_val, const int* part_idx, int n_parts, GreedyState st, int B,
                             int advance_ctx, const bf16_t* embed, bf16_t* x, int H, RopeRows rr, hipStream_t s,
                             const QuantRaw* qembed = nullptr);
+
+// Epilogue of the prompt pass's q|k|v projection as a head-tile GEMM (gemm.h MODE 2, head_dim 128): per packed position and head, q/k RMSNorm
+// over the head, RoPE at pos[m], q -> qr[m][head][128], k -> cache.k[slot[m]][kvh][pos[m]] -- the arithmetic of qk_norm_rope_wide_kernel
+// (dec_prefill.hip), element for element and in the same order, on the tile while it is still in LDS instead of a second pass over the
+// projection's output (160 MB of traffic and a launch per layer).  v heads are stored as before (qkv buffer) for the V image kernel.
+struct EpiQkHeads {
+    bf16_t* qkv; long ldo;                 // v tiles: plain bf16 store at [m][n] like EpiStoreBf16
+    bf16_t* qr;
+    KVLayout cache;
+    const int* slot; const int* pos;
+    const bf16_t* qn_w; const bf16_t* kn_w;
+    float eps;
+    const float* rope_cos; const float* rope_sin;
+    int heads, kv_heads;
+    __device__ __forceinline__ bool head_tile(int n0) const { return n0 < (heads + kv_heads) * 128; }
+    __device__ __forceinline__ void operator()(int m, int n, float4 v) const {
+        *reinterpret_cast<uint2*>(qkv + (long)m * ldo + n) = pack_bf16x4(v);
+    }
+    __device__ __forceinline__ void rows(int m0, int n0, int M, const unsigned short* T, int tid) const {
+        constexpr int HD = 128, HALF = 64;
+        const int h = n0 / HD, j = tid & 7;
+        const bf16_t* nw = h < heads ? qn_w : kn_w;
+        const uint4 w1 = *reinterpret_cast<const uint4*>(nw + 8 * j), w2 = *reinterpret_cast<const uint4*>(nw + HALF + 8 * j);
+        const bf16_t* w1e = reinterpret_cast<const bf16_t*>(&w1);
+        const bf16_t* w2e = reinterpret_cast<const bf16_t*>(&w2);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 32 + (tid >> 3);
+            const bool live = m0 + row < M;
+            const int m = live ? m0 + row : M - 1;
+            const int sw = (row >> 2) & 7;
+            const uint4 a = *reinterpret_cast<const uint4*>(T + row * 128 + ((j ^ sw) << 3));
+            const uint4 b = *reinterpret_cast<const uint4*>(T + row * 128 + (((8 + j) ^ sw) << 3));
+            const bf16_t* ae = reinterpret_cast<const bf16_t*>(&a);
+            const bf16_t* be = reinterpret_cast<const bf16_t*>(&b);
+            const int sl = slot[m], ps = pos[m];
+            float x1[8], x2[8], ss = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x1[e] = bf16_to_f32(ae[e]);
+                x2[e] = bf16_to_f32(be[e]);
+                ss += x1[e] * x1[e] + x2[e] * x2[e];
+            }
+#pragma unroll
+            for (int ofs = 1; ofs < 8; ofs <<= 1) ss += __shfl_xor(ss, ofs, 64);
+            const float inv = rsqrtf(ss / (float)HD + eps);
+            const float4* cp = reinterpret_cast<const float4*>(rope_cos + (long)ps * HALF + 8 * j);
+            const float4* sp = reinterpret_cast<const float4*>(rope_sin + (long)ps * HALF + 8 * j);
+            const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+            const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            uint4 o1, o2;
+            bf16_t* o1e = reinterpret_cast<bf16_t*>(&o1);
+            bf16_t* o2e = reinterpret_cast<bf16_t*>(&o2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float r1, r2;
+                norm_rope_pair(x1[e], x2[e], bf16_to_f32(w1e[e]), bf16_to_f32(w2e[e]), inv, cs[e], sn[e], r1, r2);
+                o1e[e] = f32_to_bf16(r1);
+                o2e[e] = f32_to_bf16(r2);
+            }
+            if (live) {
+                bf16_t* dst = h < heads ? qr + ((long)m * heads + h) * HD : cache.k + cache.off(sl, h - heads, ps);
+                *reinterpret_cast<uint4*>(dst + 8 * j) = o1;
+                *reinterpret_cast<uint4*>(dst + HALF + 8 * j) = o2;
+            }
+        }
+    }
+};
 
 // ---- epilogues for the prefill GEMMs ----------------------------------------------------------------
 // x_bf16[m][n] = bf16(x + bf16(acc))   (residual add in the decoder dtype)

@@ -231,9 +231,17 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(KVLayout cache, const 
 void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int n_pos, int heads, int kv_heads, int hd,
                          const bf16_t* qn_w, const bf16_t* kn_w, float eps, const float* rope_cos,
                          const float* rope_sin, bf16_t* qr, KVLayout cache, bf16_t* vt, int vt_stride, const int* cu,
-                         const int* slot_of_clip, int n_clips, int max_len, hipStream_t s) {
+                         const int* slot_of_clip, int n_clips, int max_len, hipStream_t s, bool v_only) {
     if (n_pos <= 0) return;
     const int nh = heads + 2 * kv_heads;
+    if (v_only) {            // q and k were handled in the projection's epilogue (EpiQkHeads): only the V images are left
+        if (hd != 128) throw std::invalid_argument("qk_norm_rope: v_only needs head_dim 128");
+        bf16_t* vt_o = (cache.vf == nullptr || tuning().pa_vfrag == 0) ? vt : nullptr;
+        if (!vt_o && !cache.vf) throw std::invalid_argument("qk_norm_rope: no V image to write");
+        hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(cdiv(max_len, 64), kv_heads, n_clips), dim3(256), 0, s, cache, qkv, nh, heads + kv_heads, cu,
+                           slot_of_clip, vt_o, vt_stride);
+        return;
+    }
     const int wide = tuning().qknr_wide;      // A/B knob
     // the prompt attention reads V^T only without the fragment image (forced aligner) or under the pa_vfrag = 0 A/B
     bf16_t* vt_out = (cache.vf == nullptr || tuning().pa_vfrag == 0) ? vt : nullptr;
@@ -257,6 +265,10 @@ void qk_norm_rope_launch(const bf16_t* qkv, const int* slot, const int* pos, int
     } else {
         throw std::invalid_argument("qk_norm_rope: unsupported (head_dim, head count)");
     }
+}
+
+bool qk_norm_rope_fusable(int heads, int kv_heads, int hd) {
+    return hd == 128 && (heads + kv_heads) % 8 == 0 && tuning().qknr_wide != 0 && tuning().pp_fuse_qk != 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -447,10 +447,16 @@ void Engine::run_prefill(bool want_logits) {
                     aligner ? nullptr : vfcache_[l]->as<bf16_t>()};
         const PromptW W = prompt_weights(l, s);
         rmsnorm_rows_launch(x, L.ln1, h, P, H, cfg_.rms_eps, s);
-        gemm_nt(ADense{h, H, P, H}, W.wqkv, H, P, nh * hd, H, EpiStoreBf16{qkv, (long)nh * hd}, s);
+        const bool fuse_qk = qk_norm_rope_fusable(cfg_.heads, cfg_.kv_heads, hd);
+        if (fuse_qk)     // q/k RMSNorm + RoPE + cache write in the projection's epilogue (head tiles), same bits as the separate launch
+            gemm_nt_headtiles(ADense{h, H, P, H}, W.wqkv, H, P, nh * hd, H,
+                              EpiQkHeads{qkv, (long)nh * hd, qr, kv, d_p_slot_, d_p_pos_, L.qn, L.kn, cfg_.rms_eps, d_rope_cos_.as<float>(),
+                                         d_rope_sin_.as<float>(), cfg_.heads, cfg_.kv_heads}, s);
+        else
+            gemm_nt(ADense{h, H, P, H}, W.wqkv, H, P, nh * hd, H, EpiStoreBf16{qkv, (long)nh * hd}, s);
         qk_norm_rope_launch(qkv, d_p_slot_, d_p_pos_, P, cfg_.heads, cfg_.kv_heads, hd, L.qn, L.kn, cfg_.rms_eps,
                             d_rope_cos_.as<float>(), d_rope_sin_.as<float>(), qr, kv, d_vt_.as<bf16_t>(), vt_stride_,
-                            d_p_cu_, d_p_slotclip_, batch_, max_len_, s);
+                            d_p_cu_, d_p_slotclip_, batch_, max_len_, s, fuse_qk);
         prefill_attention_launch(qr, kv, d_vt_.as<bf16_t>(), vt_stride_, d_p_cu_, d_p_slotclip_, batch_, max_len_,
                                  cfg_.heads, at, s);
         gemm_nt(ADense{at, nq, P, nq}, W.wo, nq, P, H, nq, EpiResidBf16{x, H}, s);

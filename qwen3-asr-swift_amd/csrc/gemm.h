@@ -267,6 +267,27 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
         }
     }
 
+    // MODE 2 (head tiles: BN = 128 = one attention head of the q|k|v projection): a tile the epilogue claims (epi.head_tile(n0): q and k heads)
+    // is rounded to bf16 into ONE 128 x 128 LDS image (32 KiB; 16-byte chunks XORed with (row >> 2) & 7 so that the four accumulator rows of
+    // a store instruction hit different banks) and handed to epi.rows(), which sees whole rows of a head -- q/k RMSNorm + RoPE + cache write run
+    // here instead of as a second pass over the projection's output (dec_kernels.h EpiQkHeads).  Other tiles (v heads) take the MODE 0 path.
+    if constexpr (MODE == 2) {
+        if (epi.head_tile(n0)) {
+            unsigned short* T = reinterpret_cast<unsigned short*>(smem);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wm * 64 + i * 16 + fc * 4 + r, col = wn * 64 + j * 16 + fr;
+                        T[row * 128 + ((((col >> 3) ^ ((row >> 2) & 7)) << 3) | (col & 7))] = f32_to_bf16(acc[i][j][r]);
+                    }
+            __syncthreads();
+            epi.rows(m0, n0, M, T, tid);
+            return;
+        }
+    }
     // epilogue through LDS so that global accesses are 16 bytes per lane along rows: the wave's 64 x 64 result in
     // HALVES passes of 64 x (64 / HALVES) floats (one pass with 64 KiB of LDS, two 32-column halves with 32 KiB)
     constexpr int HALVES = NBUF == 2 ? 1 : 2, CW = 64 / HALVES;
@@ -285,7 +306,7 @@ __device__ __forceinline__ void gemm_nt_128_body(char* __restrict__ smem /* [NBU
                 for (int r = 0; r < 4; ++r) ct[(i * 16 + fc * 4 + r) * CW + jj * 16 + fr] = acc[i][(4 / HALVES) * h + jj][r];
         __syncthreads();
         constexpr int LPR = CW / 4, RPI = 64 / LPR;         // lanes per row, rows per wave instruction
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 2) {
             const int er = lane / LPR, ec = (lane % LPR) * 4;
 #pragma unroll 4
             for (int it = 0; it < 64 / RPI; ++it) {
@@ -399,6 +420,20 @@ inline void gemm_nt(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, in
                            gemm_zero_block(), gemm_tile_rows(M, N));
     else
         hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 0>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block(), gemm_tile_rows(M, N));
+}
+
+// MODE 2 launch (see gemm_nt_128_body): N is a multiple of 128 and column tile = head; 128 x 128 forms only
+template <class ALoad, class Epi>
+inline void gemm_nt_headtiles(const ALoad& a, const bf16_t* Wt, long ldw, int M, int N, int K, const Epi& epi, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    if (N % GEMM_BN != 0) throw std::invalid_argument("head-tile gemm: N must be a multiple of 128");
+    const int grid = cdiv(M, GEMM_BM) * cdiv(N, GEMM_BN);
+    if (gemm_nbuf(grid) == 1)
+        hipLaunchKernelGGL((gemm_nt_glds1_kernel<ALoad, Epi, 2>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
+                           gemm_zero_block(), gemm_tile_rows(M, N));
+    else
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<ALoad, Epi, 2>), dim3(grid), dim3(GEMM_THREADS), 0, s, a, Wt, ldw, M, N, K, epi,
                            gemm_zero_block(), gemm_tile_rows(M, N));
 }
 

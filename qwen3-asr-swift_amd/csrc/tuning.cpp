@@ -20,7 +20,7 @@ const Entry kEntries[] = {
     {"qa_early", &Tuning::qa_early, {0, 1, 2, -1}, false}, {"qa_gate", &Tuning::qa_gate, {0, 1, -1}, false},
     {"da_waves", &Tuning::da_waves, {8, 16, -1}, false}, {"da_spec", &Tuning::da_spec, {0, 1, 2, 3, -1}, false}, {"da_earlyq", &Tuning::da_earlyq, {0, 1, -1}, false},
     {"pa_form", &Tuning::pa_form, {1, 2, -1}, false}, {"pa_mt", &Tuning::pa_mt, {1, 2, -1}, false}, {"pa_order", &Tuning::pa_order, {0, 1, -1}, false}, {"pa_vfrag", &Tuning::pa_vfrag, {0, 1, -1}, false},
-    {"qknr_wide", &Tuning::qknr_wide, {0, 1, -1}, false},
+    {"pp_fuse_qk", &Tuning::pp_fuse_qk, {0, 1, -1}, false}, {"qknr_wide", &Tuning::qknr_wide, {0, 1, -1}, false},
     {"conv_ktile", &Tuning::conv_ktile, {0, 1, -1}, false}, {"enc_attn", &Tuning::enc_attn, {0, 1, -1}, false}, {"mha_form", &Tuning::mha_form, {0, 1, 2, -1}, false},
     {"gemm_p8", &Tuning::gemm_p8, {0, 1, 2, -1}, false}, {"gemm_nbuf", &Tuning::gemm_nbuf, {0, 1, 2, -1}, false}, {"gemm_tm", &Tuning::gemm_tm, {1, 4, 8, 16, -1}, false},
     {"lmh_q_ring", &Tuning::lmh_q_ring, {0, 1, -1}, false}, {"lmh_grid", &Tuning::lmh_grid, {1, 4096, -2}, false}, {"lmh_order", &Tuning::lmh_order, {0, 1, -1}, false},

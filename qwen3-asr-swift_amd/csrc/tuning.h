@@ -35,6 +35,7 @@ struct Tuning {
     int pa_vfrag = 1;        // prompt attention V operand: 1 the decode sweep's fragment-major image (one lane-linear 16-byte read per fragment) | 0 V^T rows
     int pa_order = 1;        // prompt attention workgroup order: 1 longest query tiles first, kv head = XCD | 0 query tile fastest
     int pa_mt = 1;           // row tiles per wave of the first form
+    int pp_fuse_qk = 1;      // prompt pass: q/k RMSNorm + RoPE + cache write in the q|k|v projection's epilogue (head-tile GEMM, gemm.h MODE 2) | 0 separate launch
     int qknr_wide = 1;       // q/k norm + RoPE of the prompt pass: 16-byte accesses
     int conv_ktile = 1;      // implicit-GEMM convolutions (C >= 64): tap decomposition once per staged K-tile on the scalar unit (AConv3x3s2W) | 0 per chunk
     int enc_attn = 1;        // Qwen3 audio-encoder window attention at head_dim 64: 1 the wav2vec2 path's 32x32x16 kernel | 0 16-row kernel

@@ -71,6 +71,23 @@ def test_full_size_vs_oracle(full):
             assert d.max() <= _tol(ref) and rel < 3e-2
 
 
+def test_qk_norm_rope_in_the_projection_epilogue_is_bit_identical(full):
+    """Prompt pass: q/k RMSNorm + RoPE + cache write run in the q|k|v projection's epilogue on head tiles (gemm.h MODE 2, EpiQkHeads; knob
+    pp_fuse_qk, default) or as a separate launch over the projection's output (qk_norm_rope_wide_kernel): the same arithmetic element for
+    element -> same prompt-pass logits, same forced-step logits (the K cache rows), same tokens for a ragged batch (partial row tiles)."""
+    eng, _ = full
+    emb = P.bf16_round(torch.randn(77, 1024, generator=torch.Generator().manual_seed(11)) * 0.5).numpy()
+    clips = [synth.synth_waveform(20 + k, 0.7 + 0.31 * (k % 9)) for k in range(19)]
+    res = []
+    for fuse in (1, 0):
+        eng.set_tuning("pp_fuse_qk", fuse)
+        first = eng.prefill_logits(emb)
+        steps = eng.decode_forced([5, 77, 151643])
+        res.append((first, steps, eng.transcribe_batch(clips, max_tokens=5, ignore_eos=True)))
+    eng.set_tuning("pp_fuse_qk", 1)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
 def test_batch_invariance_and_determinism(full):
     """B = 32 (two MFMA batch tiles, the benchmark's shape) vs B = 1: identical token streams."""
     eng, sd = full
