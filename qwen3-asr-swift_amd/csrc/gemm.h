@@ -397,11 +397,12 @@ template <class A>
 struct gemm_p8_allowed<A, std::void_t<decltype(A::no_p8)>> { static constexpr bool value = !A::no_p8; };
 
 // row panels per block of the 128 x 128 forms' tile order (gemm_nt_128_body): knob gemm_tm, 1 = row-panel-major (rounds 1-3); only where the
-// launch has several blocks of that height and more column tiles than an XCD's share of a block
+// launch has several blocks of that height and at least 32 column tiles (N >= 4096: the prompt pass's q|k|v projection, -7 %; at 24 column
+// tiles -- the wav2vec2 q|k|v shape -- the blocked order measured +1.3 % on that model's transformer stage, profiles/r04_ab_gemm_order.txt)
 inline int gemm_tile_rows(int M, int N) {
     const int tm = tuning().gemm_tm;
     const int nby = cdiv(M, GEMM_BM), nbx = cdiv(N, GEMM_BN);
-    return (tm > 1 && nby >= 2 * tm && nbx > 128 / tm) ? tm : 1;
+    return (tm > 1 && nby >= 2 * tm && nbx >= 32) ? tm : 1;
 }
 
 template <class ALoad, class Epi>
