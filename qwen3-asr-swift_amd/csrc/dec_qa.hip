@@ -75,8 +75,11 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         for (int i = 0; i < 4; ++i) xr[p][i] = *reinterpret_cast<const uint4*>(xp + i * 32 * 8);
     }
     uint4 wC[1][4];
+    auto request_w = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wC[0][i] = *reinterpret_cast<const uint4*>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
+        for (int i = 0; i < 4; ++i) wC[0][i] = *reinterpret_cast<const uint4*>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
+    };
+    if constexpr (EARLY != 4) request_w();
 
     const bf16_t* kb = cache.k + cache.off(bq, kvh, 0) + g * 8;
     const bf16_t* vfb = cache.vf + cache.off(bq, kvh, 0) + lane * 8;
@@ -107,8 +110,11 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             vreg[u][dt] = *reinterpret_cast<const uint4*>(has_att ? vfb + ((long)ch_early[u] * DT + dt) * 512 : kdummy);
     };
     // (wave 0 may take part: its 8 requests have landed long before its drain)
-    const bool early_wave = EARLY == 1 || (EARLY == 2 && wave >= 4);
-    if constexpr (EARLY != 0) { if (early_wave) request_k(0); }
+    // EARLY 3: the same request from every wave once its activation rows have left for LDS (chain_mma's after-stage hook); 4: before the
+    // weight tile instead of behind it
+    const bool early_wave = EARLY == 1 || EARLY == 3 || EARLY == 4 || (EARLY == 2 && wave >= 4);
+    if constexpr (EARLY == 1 || EARLY == 2 || EARLY == 4) { if (early_wave) request_k(0); }
+    if constexpr (EARLY == 4) request_w();
     if (tid < 128) reinterpret_cast<uint4*>(dsm + L_NORM)[tid] = nw;
     __syncthreads();
 
@@ -121,7 +127,8 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         }
     {
         f32x4 acc[1][NB];
-        chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1);
+        auto hook = [&]() { if constexpr (EARLY == 3) request_k(0); };
+        chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1, hook);
         auto rest = [&]() { if (!early_wave) request_k(0); request_v(0); request_k(1); request_v(1); };
         if constexpr (!GATE) { if (wave != 0) rest(); }
         if (wave == 0) {
@@ -379,13 +386,16 @@ void decode_qa_launch(const DecQaArgs& a0, hipStream_t s) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k), L_TOTAL);
         hipLaunchKernelGGL(k, dim3(256), dim3(CT), L_TOTAL, s, a);
     };
-    const int early = tuning().qa_early, gate = tuning().qa_gate;
+    // 5 = by batch: more than 16 rows -> 3 (behind the staging), else 4 (in front of the weight tile): profiles/r04_ab_fused_layer.txt
+    const int early = tuning().qa_early == 5 ? (a.B > 16 ? 3 : 4) : tuning().qa_early, gate = tuning().qa_gate;
 #define QA_GO(E_, G_)                                                                                                   \
     do {                                                                                                                  \
         if (a.dbg) { if (a.B <= 16) go(decode_qa_kernel<1, true, E_, G_>); else go(decode_qa_kernel<2, true, E_, G_>); }  \
         else { if (a.B <= 16) go(decode_qa_kernel<1, false, E_, G_>); else go(decode_qa_kernel<2, false, E_, G_>); }      \
     } while (0)
     if (early == 0) { if (gate) QA_GO(0, 1); else QA_GO(0, 0); }
+    else if (early == 3) QA_GO(3, 0);
+    else if (early == 4) QA_GO(4, 0);
     else if (early == 2) { if (gate) QA_GO(2, 1); else QA_GO(2, 0); }
     else { if (gate) QA_GO(1, 1); else QA_GO(1, 0); }
 #undef QA_GO

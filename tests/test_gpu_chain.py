@@ -82,13 +82,13 @@ def test_qa_request_schedules_agree(eng):
     want = [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)]
     eng.set_tuning("qa", 1)
     try:
-        for early in (0, 1, 2):
-            for gate in (0, 1):
+        for early, gate in ((0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (4, 0)):
+            if True:
                 eng.set_tuning("qa_early", early)
                 eng.set_tuning("qa_gate", gate)
                 assert [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)] == want, (early, gate)
     finally:
-        eng.set_tuning("qa_early", 1)
+        eng.set_tuning("qa_early", 5)
         eng.set_tuning("qa_gate", 0)
         eng.set_tuning("qa", 1)
 
