@@ -132,6 +132,22 @@ __device__ __forceinline__ float lane_sum(float p) {
     return p;
 }
 
+// max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (one per 16-lane row), on every lane: two permlane swaps instead of the two
+// ds_bpermute round trips that __shfl_xor(., 16) and __shfl_xor(., 32) cost (the decode attention's per-chunk score maximum).  Exact for max;
+// the sum adds the same pairs as the shuffle form (x + x^16, then + the other half), so it is bit-identical to it.
+__device__ __forceinline__ float rows4_max(float p) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+    p = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+    return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+}
+__device__ __forceinline__ float rows4_sum(float p) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+    p = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
 // maximum over aligned groups of 16 adjacent lanes, on every lane of the group (same DPP steps)
 __device__ __forceinline__ float lane_max16(float p) {
     p = fmaxf(p, dpp_mov_f32<0xB1>(p));

@@ -218,8 +218,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
                         sc[h][j] = v;
                         mx = fmaxf(mx, v);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = rows4_max(mx);
                 const float m_new = fmaxf(m_run, mx);                    // finite: a chunk below nchunks has a valid key
                 const float alpha = __expf(m_run - m_new);
                 float rsum = 0.0f;
@@ -260,8 +259,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_mfma_kernel(
         }
     }
     QASR_STAMP(2);
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = rows4_sum(l_run);
     if (lane < REP) { s_m[wave][lane] = m_run; s_l[wave][lane] = l_run; }
     if (g == 0) {
 #pragma unroll

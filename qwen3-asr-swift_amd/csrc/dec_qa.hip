@@ -286,8 +286,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
                         sc[h][j] = v;
                         mx = fmaxf(mx, v);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = rows4_max(mx);
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = __expf(m_run - m_new);
                 float rsum = 0.0f;
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         }
     }
     QA_STAMP(6, 64);
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = rows4_sum(l_run);
     if (lane < REP) { s_m[wave * REP + lane] = m_run; s_l[wave * REP + lane] = l_run; }
     if (g == 0) {
 #pragma unroll
