@@ -317,6 +317,9 @@ void decode_attention_launch(const bf16_t* qkv, const int* ctx_len, int B, int h
     hipLaunchKernelGGL((decode_attention_mfma_kernel<HD_, W_, U_, S_, E_>), grid, dim3(W_ * 64), 0, s, qkv, ctx_len, heads, kv_heads, \
                        qn_w, kn_w, eps, rope_cos, rope_sin, cache, out, scale, dbg)
     if (hd == 128) {
+        if ((tuning().da_unr == 1 || tuning_thread_is_shared()) && nw == 8) {       // one chunk in flight per wave: ~130 registers, two such workgroups (or one + a GEMV's) share a CU
+            if (spec) QASR_DAM_GO(128, 8, 1, 1, false); else QASR_DAM_GO(128, 8, 1, 0, false);
+        } else
         if (nw == 16) { if (spec) QASR_DAM_GO(128, 16, 1, 2, true); else QASR_DAM_GO(128, 16, 1, 0, true); }
         else if (early) { if (spec == 2) QASR_DAM_GO(128, 8, 2, 2, true); else if (spec == 1) QASR_DAM_GO(128, 8, 2, 1, true); else QASR_DAM_GO(128, 8, 2, 0, true); }
         else { if (spec == 2) QASR_DAM_GO(128, 8, 2, 2, false); else if (spec == 1) QASR_DAM_GO(128, 8, 2, 1, false); else QASR_DAM_GO(128, 8, 2, 0, false); }

@@ -596,6 +596,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
     bf16_t* at = d_dattn_.as<bf16_t>() + (size_t)r0 * nq;
     bf16_t* act = d_dact_.as<bf16_t>() + (size_t)r0 * I;
     const GreedyState gs = greedy_rows(r0);
+    struct SharedScope { bool on; SharedScope(bool s) : on(s) { if (on) tuning_thread_shared(true); } ~SharedScope() { if (on) tuning_thread_shared(false); } } shared_scope(shared_device_);
     // chain > 0: a layer's linears run as one persistent launch (dec_chain.hip) wherever it has an instantiation: the float 0.6B geometry,
     // the whole batch in one row group (the arrival counters belong to one step of one engine), up to 32 rows
     const int chain = step_chain(r0, nr);

@@ -27,6 +27,7 @@ struct Tuning {
                              // ends with QASR_ERR_HIP (tests/test_gpu_chain.py::test_lost_arrival_ends_in_an_error_not_a_hang)
     int chain_proto = 0;     // chain arrival counters: 0 sharded (add to one of 8, poll all 8) | 1 replicated (add to all 8, poll one)
     int chain_pf = 0;        // chain weight requests: 0 every phase's tiles at kernel entry | 1 staged (first phase first)
+    int da_unr = 2;          // stand-alone decode attention, 8 waves: chunks in flight per wave 2 | 1 (~130 registers: shares a CU; for engines that share a GPU)
     int da_waves = 8;        // decode attention waves per workgroup (8 with two chunks in flight | 16 with one)
     int da_spec = 3;         // K/V requests issued before ctx_len is known: 0 none | 1 each wave's first chunk (no byte past the context at 256+ keys) |
                              // 2 every chunk of the first round (1.26 x the algorithmic bytes at 32 x 30 s) | 3 = 2 up to 8 batch rows, 1 above
@@ -60,6 +61,10 @@ struct Tuning {
 };
 
 Tuning& tuning();                                   // process-wide; first call seeds it from the environment
+// Set by an engine around the launches of a decode step on the CALLING thread: the engine shares its GPU with other engines (qasr_dp lanes),
+// so kernels that leave room on a CU are preferred (one-chunk attention, four-wave K = 1024 GEMVs: +2.5 % with three lanes, -0.7 % alone)
+void tuning_thread_shared(bool shared);
+bool tuning_thread_is_shared();
 bool tuning_set(const char* key, int value);        // false: unknown key, or a value outside the knob's enumerated / ranged set
 bool tuning_get(const char* key, int* value);
 
