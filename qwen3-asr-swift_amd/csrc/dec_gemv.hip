@@ -429,7 +429,7 @@ static bool gemv2_k(const DecGemv2Args& a2, hipStream_t s) {
     // (K -> waves x k-steps per wave): wide workgroups for the small-N / large-K matrices
     switch (a2.g.K) {
         case 1024: {
-            const bool w8 = tuning().gemv_w1024 == 8 && !tuning_thread_is_shared();   // A/B knob (8 waves x 4 k-steps won)
+            const bool w8 = tuning().gemv_w1024 == 8;   // A/B knob (8 waves x 4 k-steps won)
             if constexpr (EPI == DEC_EPI_LOGITS) return gemv2_nb<NT, 8, 4, PRO, EPI>(a2, s);
             else return w8 ? gemv2_nb<NT, 8, 4, PRO, EPI>(a2, s) : gemv2_nb<NT, 4, 8, PRO, EPI>(a2, s);
         }

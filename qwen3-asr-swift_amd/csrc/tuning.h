@@ -62,7 +62,7 @@ struct Tuning {
 
 Tuning& tuning();                                   // process-wide; first call seeds it from the environment
 // Set by an engine around the launches of a decode step on the CALLING thread: the engine shares its GPU with other engines (qasr_dp lanes),
-// so kernels that leave room on a CU are preferred (one-chunk attention, four-wave K = 1024 GEMVs: +2.5 % with three lanes, -0.7 % alone)
+// so kernels that leave room on a CU are preferred: the one-chunk attention (same chunk -> wave map, bit-identical; +2 % with three lanes, -0.3 % alone)
 void tuning_thread_shared(bool shared);
 bool tuning_thread_is_shared();
 bool tuning_set(const char* key, int value);        // false: unknown key, or a value outside the knob's enumerated / ranged set
