@@ -187,8 +187,32 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         wk = ld4_sc1(row + (long)(QA_HEADS + kvh) * HD + 2 * lane);
         wv = ld4_sc1(row + (long)(QA_HEADS + QA_KVH + kvh) * HD + 2 * lane);
         const float rc = a.rope_cos[(long)b * HALF + lane], rs = a.rope_sin[(long)b * HALF + lane];
-        const float w1 = bf16_to_f32(a.qn_w[lane]), w2 = bf16_to_f32(a.qn_w[lane + HALF]);
-        const float kw1 = bf16_to_f32(a.kn_w[lane]), kw2 = bf16_to_f32(a.kn_w[lane + HALF]);
+        const bf16_t w1r = a.qn_w[lane], w2r = a.qn_w[lane + HALF], kw1r = a.kn_w[lane], kw2r = a.kn_w[lane + HALF];
+        // wave 0's remaining chunk requests go out BEHIND its own-row requests (which therefore come back first: loads return in order) and
+        // before anything uses them -- the query preparation below then runs while these chunks fly, instead of in front of their request
+        // (unconditional, on the clamped chunk indices: a request under a branch would make hipcc wait for ALL of them at the rows' first use)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            constexpr bool W0_EARLY = EARLY == 1 || EARLY == 3 || EARLY == 4;      // wave 0's first K half came in with everybody's
+            if constexpr (!W0_EARLY) {
+                const bf16_t* kr = kb + ((long)ch_early[0] * 32 + fr) * HD;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kreg[0][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vreg[0][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[0] * DT + dt) * 512);
+            const bf16_t* kr = kb + ((long)ch_early[1] * 32 + fr) * HD;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kreg[1][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vreg[1][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[1] * DT + dt) * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float w1 = bf16_to_f32(w1r), w2 = bf16_to_f32(w2r), kw1 = bf16_to_f32(kw1r), kw2 = bf16_to_f32(kw2r);
         auto pick = [&](unsigned w, int src_lane) {
             const unsigned v = (unsigned)__shfl((int)w, src_lane, 64);
             return (bf16_t)((lane & 1) ? v >> 16 : v & 0xffffu);
@@ -223,27 +247,6 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             const int i = lane + 64 * ii;
             s_vn[i] = bf16_to_f32(vown[ii]);
             dvf[qa_vfrag_index<HD>(pos, i)] = vown[ii];
-        }
-        // the rest of wave 0's chunks (its first K half came in with everybody's)
-        if (wave < nchunks) {
-            if (!early_wave) {
-                const bf16_t* kr = kb + ((long)ch_early[0] * 32 + fr) * HD;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) kreg[0][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vreg[0][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[0] * DT + dt) * 512);
-        }
-        if (wave + WAVES < nchunks) {
-            const bf16_t* kr = kb + ((long)ch_early[1] * 32 + fr) * HD;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kreg[1][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vreg[1][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[1] * DT + dt) * 512);
         }
     }
     __syncthreads();
