@@ -14,6 +14,9 @@ constexpr int CHAIN_SEAMS = 4;            // o -> gate|up, gate|up -> down, down
 constexpr int CHAIN_SHARDS = 8;           // arrival counters are sharded over 8 lines (fan-in of up to 192 producers)
 constexpr int CHAIN_SHARD_WORDS = 32;     // one 128-byte line per shard
 constexpr size_t CHAIN_CTR_BYTES = (size_t)CHAIN_SEAMS * CHAIN_SHARDS * CHAIN_SHARD_WORDS * sizeof(unsigned);
+// behind the counters, on a line of its own: the step sequence word (never zeroed; bumped once in front of every step's fused launches)
+constexpr int CHAIN_SEQ_WORD = (int)(CHAIN_CTR_BYTES / sizeof(unsigned)) + CHAIN_SHARD_WORDS;
+constexpr size_t CHAIN_STATE_BYTES = CHAIN_CTR_BYTES + 2 * CHAIN_SHARD_WORDS * sizeof(unsigned);
 constexpr int CHAIN_ERR_TIMEOUT = 2;      // bit set in *err when a hand-off wait gave up (host: QASR_ERR_HIP)
 
 struct DecChainArgs {
@@ -54,7 +57,14 @@ struct DecQaArgs {
     int* err;
     unsigned long long* dbg = nullptr;   // diagnostic: [256][32] phase stamps (qasr_kernel_probe 7), null in product launches
     int fault = 0;          // test only (knob chain_fault): workgroup 5 never signals -> the bounded waits must end the step with CHAIN_ERR_TIMEOUT
+    // hand-off form (knob qa_gran): non-null = the projected rows travel as 8-byte {two bf16 values, tag} granules and the data IS the flag
+    // (cdna_hip_programming.md Guideline 16, R2): no drain, no counter, no second round trip for the rows.  [32 rows][QA_GRAN_ROW] granules;
+    // tag = (ctr[CHAIN_SEQ_WORD] << 8) | (epoch + 1): the sequence word is bumped by whatever zeroes the counters in front of a step
+    // (greedy_finalize_kernel, decode_chain_reset), so a tag never equals what an earlier step or layer left in the buffer
+    unsigned long long* gran = nullptr;
 };
+constexpr int QA_GRAN_ROW = 2048;                                   // granules per batch row (4096 projected values)
+constexpr size_t QA_GRAN_BYTES = (size_t)32 * QA_GRAN_ROW * 8;
 bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_ctx);
 void decode_qa_launch(const DecQaArgs& a, hipStream_t s);
 

@@ -283,6 +283,11 @@ void decode_chain_launch(int phases, const DecChainArgs& a, hipStream_t s) {
     else { if (pf) chain_ph<2, true>(phases, b, s); else chain_ph<2, false>(phases, b, s); }
 }
 
-void decode_chain_reset(unsigned* ctr, hipStream_t s) { QASR_HIP(hipMemsetAsync(ctr, 0, CHAIN_CTR_BYTES, s)); }
+// zero the arrival counters and bump the step sequence word (what greedy_finalize_kernel does in front of a greedy step)
+__global__ __launch_bounds__(256) void chain_reset_kernel(unsigned* ctr) {
+    for (int i = threadIdx.x; i < (int)(CHAIN_CTR_BYTES / sizeof(unsigned)); i += 256) ctr[i] = 0u;
+    if (threadIdx.x == 0) ctr[CHAIN_SEQ_WORD] += 1u;
+}
+void decode_chain_reset(unsigned* ctr, hipStream_t s) { hipLaunchKernelGGL(chain_reset_kernel, dim3(1), dim3(256), 0, s, ctr); }
 
 }  // namespace qasr

@@ -119,7 +119,7 @@ struct GreedyState {
     int eos;
     int ignore_eos;
     int vocab;          // ids outside [0, vocab) (all-NaN logits) are clamped to 0 so the gather cannot fault, and *err is set
-    unsigned* clear = nullptr;   // words zeroed by every finalize launch: the arrival counters of the NEXT step's fused launches (dec_chain.h) --
+    unsigned* clear = nullptr;   // (the word 32 behind them is the step sequence word, incremented instead)  words zeroed by every finalize launch: the arrival counters of the NEXT step's fused launches (dec_chain.h) --
     int clear_words = 0;         // a greedy step is always preceded by a finalize, so its graph needs no memset node (4.7 us per step)
 };
 // rope rows of the next decode position, one per batch row (cos_rows/sin_rows [B][half]), copied from the

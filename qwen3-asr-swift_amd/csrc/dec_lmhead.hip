@@ -268,8 +268,10 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
     __shared__ float s_v[256];
     __shared__ int s_i[256];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (b == 0)
+    if (b == 0) {
         for (int i = tid; i < st.clear_words; i += 256) st.clear[i] = 0u;
+        if (tid == 0 && st.clear_words) st.clear[st.clear_words + 32] += 1u;      // the step sequence word (dec_chain.h CHAIN_SEQ_WORD)
+    }
     // position of the NEXT decode step for this row; its rope row is copied next to the batch row so that
     // the attention kernels of that step need not chain a table lookup behind the ctx_len load
     const int next_pos = st.ctx_len[b] + (advance_ctx ? 1 : 0);

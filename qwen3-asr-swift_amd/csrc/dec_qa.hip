@@ -44,7 +44,10 @@ __device__ __forceinline__ long qa_vfrag_index(int key, int d) {       // = vfra
 // EARLY: which waves request the K half of their first chunk before the projection: 0 none | 1 all | 2 waves 4..7 (A/B, knob qa_early).
 // GATE: 1 = waves 1..7 hold their remaining requests until wave 0 has stored, drained and signalled the projection (so that the hand-off's
 //       write-through stores are not queued behind the stream) | 0 = they request as soon as the sums are in (knob qa_gate).
-template <int NB, bool ST, int EARLY, int GATE>
+// GRAN: 1 = the hand-off as data-tagged granules (DecQaArgs::gran): wave 0 stores {two values, tag} words straight from the sums -- no drain, no
+//       counter -- and the consumer's wave 0 re-reads ITS 256 granules until every tag is this launch's: the poll and the rows' fetch are one
+//       round trip | 0 = write-through rows + one arrival counter per kv head + sc1 row loads (the first form; knob qa_gran).
+template <int NB, bool ST, int EARLY, int GATE, int GRAN>
 __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     constexpr int HD = QA_HD, REP = 2, KS = HD / 32, DT = HD / 16, HALF = HD / 2, WAVES = CWAVES, UNR = QA_UNR;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
@@ -65,6 +68,8 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
 
     // ---- requests, oldest first: context length, norm weights, activation rows, weight tile, then the K / V chunks ------------------
     int pos = a.ctx_len[bq];
+    unsigned tag = 0;
+    if constexpr (GRAN) tag = (a.ctr[CHAIN_SEQ_WORD] << 8) | (a.epoch + 1u);      // written by an earlier launch (finalize / reset): plain load
     const uint4 nw = reinterpret_cast<const uint4*>(a.ln1)[tid & 127];
     uint4 xr[NB][4];
 #pragma unroll
@@ -132,16 +137,32 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         auto rest = [&]() { if (!early_wave) request_k(0); request_v(0); request_k(1); request_v(1); };
         if constexpr (!GATE) { if (wave != 0) rest(); }
         if (wave == 0) {
+            if constexpr (GRAN) {
+                // two granules per lane and row tile: values (4 fc, 4 fc + 1) and (4 fc + 2, 4 fc + 3) of tile wg, each ONE aligned 8-byte store
+                if (!(a.fault && wg == 5)) {
 #pragma unroll
-            for (int p = 0; p < NB; ++p) {
-                const int row = p * 16 + fr;
-                if (row < B)
-                    st8_sc1(a.qkv + (long)row * QA_NQKV + wg * 16 + fc * 4,
-                            pack_bf16x4(make_float4(acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3])));
+                    for (int p = 0; p < NB; ++p) {
+                        const int row = p * 16 + fr;
+                        if (row < B) {
+                            const uint2 v = pack_bf16x4(make_float4(acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3]));
+                            unsigned long long* gp = a.gran + (long)row * QA_GRAN_ROW + wg * 8 + fc * 2;
+                            __hip_atomic_store(gp, ((unsigned long long)tag << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(gp + 1, ((unsigned long long)tag << 32) | v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NB; ++p) {
+                    const int row = p * 16 + fr;
+                    if (row < B)
+                        st8_sc1(a.qkv + (long)row * QA_NQKV + wg * 16 + fc * 4,
+                                pack_bf16x4(make_float4(acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3])));
+                }
+                // tile -> kv head it feeds: q columns (tiles 0..127, 16 per kv head), then k (8 per head), then v
+                const int grp = wg < 128 ? wg >> 4 : (wg < 192 ? (wg - 128) >> 3 : (wg - 192) >> 3);
+                if (!(a.fault && wg == 5)) seam_signal(a.ctr, 3, grp);
             }
-            // tile -> kv head it feeds: q columns (tiles 0..127, 16 per kv head), then k (8 per head), then v
-            const int grp = wg < 128 ? wg >> 4 : (wg < 192 ? (wg - 128) >> 3 : (wg - 192) >> 3);
-            if (!(a.fault && wg == 5)) seam_signal(a.ctr, 3, grp);
             QA_STAMP(3, 0);
         }
         if constexpr (GATE) {
@@ -150,8 +171,10 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         }
     }
     if (!has_att) return;
-    if (!seam_wait_n(a.ctr + (3 * CHAIN_SHARDS + kvh) * CHAIN_SHARD_WORDS, 1, (a.epoch + 1) * 32, a.err, s_flag)) return;
-    QA_STAMP(4, 0);
+    if constexpr (!GRAN) {
+        if (!seam_wait_n(a.ctr + (3 * CHAIN_SHARDS + kvh) * CHAIN_SHARD_WORDS, 1, (a.epoch + 1) * 32, a.err, s_flag)) return;
+        QA_STAMP(4, 0);
+    }
 
     // ---- attention unit (b, kvh): decode_attention_mfma_kernel's body with the first round of K / V already requested -----------------
     auto issue = [&](int chunk0, int limit) {
@@ -180,12 +203,44 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     if (wave == 0) {
         // the token's own rows: handed-off bytes -> sc1 loads, one dword (two elements) per lane, then a lane permute puts element `lane`
         // and element `lane + 64` on every lane like the two-byte loads of the stand-alone kernel
-        const bf16_t* row = a.qkv + (long)b * QA_NQKV;
         unsigned wq[REP], wk, wv;
+        if constexpr (GRAN) {
+            // the sweep: this unit's 4 x 64 granules (lane <-> values 2 lane, 2 lane + 1 of a 128-value row) until every tag is this launch's;
+            // the error word rides along, so that a step which has lost an arrival fails every later wait at its first pass
+            const unsigned long long* gr = a.gran + (long)b * QA_GRAN_ROW + lane;
+            const unsigned long long t0 = wall_clock64();
+            bool ok;
+            for (;;) {
+                unsigned long long x[REP + 2];
 #pragma unroll
-        for (int r = 0; r < REP; ++r) wq[r] = ld4_sc1(row + (long)(kvh * REP + r) * HD + 2 * lane);
-        wk = ld4_sc1(row + (long)(QA_HEADS + kvh) * HD + 2 * lane);
-        wv = ld4_sc1(row + (long)(QA_HEADS + QA_KVH + kvh) * HD + 2 * lane);
+                for (int r = 0; r < REP; ++r) x[r] = __hip_atomic_load(gr + (kvh * REP + r) * (HD / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x[REP] = __hip_atomic_load(gr + (QA_HEADS + kvh) * (HD / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x[REP + 1] = __hip_atomic_load(gr + (QA_HEADS + QA_KVH + kvh) * (HD / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned e = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool mine = true;
+#pragma unroll
+                for (int r = 0; r < REP + 2; ++r) mine &= (unsigned)(x[r] >> 32) == tag;
+#pragma unroll
+                for (int r = 0; r < REP; ++r) wq[r] = (unsigned)x[r];
+                wk = (unsigned)x[REP];
+                wv = (unsigned)x[REP + 1];
+                const bool dead = (e & CHAIN_ERR_TIMEOUT) != 0;
+                ok = !dead && __builtin_amdgcn_ballot_w64(!mine) == 0;
+                if (ok || dead || wall_clock64() - t0 > CH_SPIN_TICKS) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) {
+                *s_flag = ok ? 1 : 0;
+                if (!ok) atomicOr(a.err, CHAIN_ERR_TIMEOUT);
+            }
+            QA_STAMP(4, 0);
+        } else {
+            const bf16_t* row = a.qkv + (long)b * QA_NQKV;
+#pragma unroll
+            for (int r = 0; r < REP; ++r) wq[r] = ld4_sc1(row + (long)(kvh * REP + r) * HD + 2 * lane);
+            wk = ld4_sc1(row + (long)(QA_HEADS + kvh) * HD + 2 * lane);
+            wv = ld4_sc1(row + (long)(QA_HEADS + QA_KVH + kvh) * HD + 2 * lane);
+        }
         const float rc = a.rope_cos[(long)b * HALF + lane], rs = a.rope_sin[(long)b * HALF + lane];
         const bf16_t w1r = a.qn_w[lane], w2r = a.qn_w[lane + HALF], kw1r = a.kn_w[lane], kw2r = a.kn_w[lane + HALF];
         // wave 0's remaining chunk requests go out BEHIND its own-row requests (which therefore come back first: loads return in order) and
@@ -250,6 +305,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         }
     }
     __syncthreads();
+    if constexpr (GRAN) { if (*s_flag == 0) return; }                 // the sweep gave up (uniform: read behind the barrier)
     if constexpr (ST) { if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     QA_STAMP(5, 64);
     mfma_bf16x8 qf[KS];
@@ -389,17 +445,21 @@ void decode_qa_launch(const DecQaArgs& a0, hipStream_t s) {
     };
     // 5 = by batch: more than 16 rows -> 3 (behind the staging), else 4 (in front of the weight tile): profiles/r04_ab_fused_layer.txt
     const int early = tuning().qa_early == 5 ? (a.B > 16 ? 3 : 4) : tuning().qa_early, gate = tuning().qa_gate;
-#define QA_GO(E_, G_)                                                                                                   \
-    do {                                                                                                                  \
-        if (a.dbg) { if (a.B <= 16) go(decode_qa_kernel<1, true, E_, G_>); else go(decode_qa_kernel<2, true, E_, G_>); }  \
-        else { if (a.B <= 16) go(decode_qa_kernel<1, false, E_, G_>); else go(decode_qa_kernel<2, false, E_, G_>); }      \
+    const bool gran = tuning().qa_gran != 0 && a.gran != nullptr;
+    if (!gran) a.gran = nullptr;
+#define QA_GO2(E_, G_, R_)                                                                                                      \
+    do {                                                                                                                          \
+        if (a.dbg) { if (a.B <= 16) go(decode_qa_kernel<1, true, E_, G_, R_>); else go(decode_qa_kernel<2, true, E_, G_, R_>); }  \
+        else { if (a.B <= 16) go(decode_qa_kernel<1, false, E_, G_, R_>); else go(decode_qa_kernel<2, false, E_, G_, R_>); }      \
     } while (0)
+#define QA_GO(E_, G_) do { if (gran) QA_GO2(E_, G_, 1); else QA_GO2(E_, G_, 0); } while (0)
     if (early == 0) { if (gate) QA_GO(0, 1); else QA_GO(0, 0); }
-    else if (early == 3) QA_GO(3, 0);
-    else if (early == 4) QA_GO(4, 0);
+    else if (early == 3) { if (gate) QA_GO(3, 1); else QA_GO(3, 0); }
+    else if (early == 4) { if (gate) QA_GO(4, 1); else QA_GO(4, 0); }
     else if (early == 2) { if (gate) QA_GO(2, 1); else QA_GO(2, 0); }
     else { if (gate) QA_GO(1, 1); else QA_GO(1, 0); }
 #undef QA_GO
+#undef QA_GO2
 }
 
 }  // namespace qasr

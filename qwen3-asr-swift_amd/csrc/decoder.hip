@@ -270,8 +270,10 @@ void Engine::finalize_decoder() {
     d_dqkv_.alloc((size_t)B * nh * hd * 2);
     d_dattn_.alloc((size_t)B * nq * 2);
     d_dact_.alloc((size_t)B * I * 2);
-    d_chain_ctr_.alloc(CHAIN_CTR_BYTES);
-    QASR_HIP(hipMemsetAsync(d_chain_ctr_.p, 0, CHAIN_CTR_BYTES, stream_));
+    d_chain_ctr_.alloc(CHAIN_STATE_BYTES);
+    QASR_HIP(hipMemsetAsync(d_chain_ctr_.p, 0, CHAIN_STATE_BYTES, stream_));
+    d_qa_gran_.alloc(QA_GRAN_BYTES);
+    QASR_HIP(hipMemsetAsync(d_qa_gran_.p, 0, QA_GRAN_BYTES, stream_));
     d_logits_.alloc((size_t)B * cfg_.vocab * sizeof(float));
     n_parts_ = decw_.quant ? lm_head_q_parts(cfg_.vocab, H, cfg_.bits) : lm_head_parts(cfg_.vocab, H);
     const int parts_cap = std::max(n_parts_, decode_gemv_blocks(DEC_EPI_LOGITS, cfg_.vocab));
@@ -620,6 +622,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
             DecQaArgs q{x, L.ln1, L.wqkv_p, qkv, gs.ctx_len, L.qn, L.kn, rr.cos_rows, rr.sin_rows, kv, at, nr, cfg_.rms_eps,
                         1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_,
                         (qa_dbg_ && l == cfg_.dec_layers / 2) ? qa_dbg_ : nullptr};
+            q.gran = d_qa_gran_.as<unsigned long long>();
             decode_qa_launch(q, s);
         } else {
             if (chain < 3 || l == 0) {         // chain 3: layer l's q|k|v came out of layer l - 1's launch
@@ -1021,6 +1024,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                 decode_chain_reset(d_chain_ctr_.as<unsigned>(), s);
                 DecQaArgs q{d_dx_.as<bf16_t>(), Lq.ln1, Lq.wqkv_p, d_dqkv_.as<bf16_t>(), gstate_.ctx_len, Lq.qn, Lq.kn, rr.cos_rows, rr.sin_rows,
                             kvl, d_dattn_.as<bf16_t>(), rows, cfg_.rms_eps, 1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), 0u, d_err_flag_};
+                q.gran = d_qa_gran_.as<unsigned long long>();
                 if (probe_ev) QASR_HIP(hipEventRecord(probe_ev[0], s));
                 decode_qa_launch(q, s);
                 if (probe_ev) QASR_HIP(hipEventRecord(probe_ev[1], s));

@@ -22,6 +22,7 @@ struct Tuning {
     int qa_early = 5;        // dec_qa: when the K half of each wave's first chunk is requested: 0 with the rest (after the projection's sums) | 1 behind the
                              // weight tile | 2 like 1 on waves 4..7 only | 3 once the wave's activation rows are staged | 4 in front of the weight tile |
                              // 5 (default) 3 above 16 batch rows, 4 up to 16
+    int qa_gran = 1;         // dec_qa hand-off: 1 data-tagged 8-byte granules (the data is the flag) | 0 write-through rows + arrival counter + sc1 row loads
     int qa_gate = 0;         // dec_qa: 1 waves 1..7 hold their remaining K / V requests until wave 0 has signalled the projection | 0 as soon as the sums are in
     int chain_fault = 0;     // TEST ONLY: 1 = one workgroup of the fused q|k|v + attention launch never signals, so the bounded waits give up and the step
                              // ends with QASR_ERR_HIP (tests/test_gpu_chain.py::test_lost_arrival_ends_in_an_error_not_a_hang)

@@ -26,6 +26,7 @@ def eng():
     e.set_tuning("chain_proto", 0)
     e.set_tuning("chain_pf", 0)
     e.set_tuning("qa", 1)
+    e.set_tuning("qa_gran", 1)
     e.close()
 
 
@@ -45,16 +46,18 @@ def test_chain_equals_five_launch_layer_bit_for_bit(eng, proto, pf):
     eng.set_tuning("chain_pf", pf)
     base = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
     assert len({tuple(t) for t in base[2][-1]}) > 1            # the rows do differ
-    for mode, qa in ((1, 0), (2, 0), (3, 0), (0, 1), (2, 1)):
+    for mode, qa in ((1, 0), (2, 0), (3, 0), (0, 1), (2, 1), (0, 2)):
         eng.set_tuning("chain", mode)
-        eng.set_tuning("qa", qa)
+        eng.set_tuning("qa", min(qa, 1))
+        eng.set_tuning("qa_gran", 0 if qa == 2 else 1)            # qa 2 here: the fused launch with its first hand-off form (counter + row loads)
         got = _run(eng, clips, emb, [11, 151643, 5, 9000, 77])
         assert np.array_equal(got[0], base[0]), (mode, qa)
         assert np.array_equal(got[1], base[1]), (mode, qa, float(np.abs(got[1] - base[1]).max()))
         for b, (g, w) in zip((1, 8, 16, 17, 32), zip(got[2], base[2])):
             assert g == w, (mode, qa, b)
     eng.set_tuning("chain", 0)
-    eng.set_tuning("qa", 1)                                    # the library's default
+    eng.set_tuning("qa", 1)                                    # the library's defaults
+    eng.set_tuning("qa_gran", 1)
 
 
 def test_chain_natural_eos_and_reruns(eng):
@@ -82,18 +85,21 @@ def test_qa_request_schedules_agree(eng):
     want = [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)]
     eng.set_tuning("qa", 1)
     try:
-        for early, gate in ((0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (4, 0)):
-            if True:
+        for gran in (1, 0):
+            eng.set_tuning("qa_gran", gran)
+            for early, gate in ((0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1), (4, 0), (4, 1)):
                 eng.set_tuning("qa_early", early)
                 eng.set_tuning("qa_gate", gate)
-                assert [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)] == want, (early, gate)
+                assert [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)] == want, (gran, early, gate)
     finally:
         eng.set_tuning("qa_early", 5)
         eng.set_tuning("qa_gate", 0)
+        eng.set_tuning("qa_gran", 1)
         eng.set_tuning("qa", 1)
 
 
-def test_lost_arrival_ends_in_an_error_not_a_hang(eng):
+@pytest.mark.parametrize("gran", [1, 0], ids=["tagged-granules", "arrival-counter"])
+def test_lost_arrival_ends_in_an_error_not_a_hang(eng, gran):
     """Every in-launch wait is bounded by a wall-clock budget (200 ms): with one workgroup's arrival withheld (test knob chain_fault) the
     waiting workgroups give up, the step's later waits fail at their first poll, qasr_batch_tokens reports QASR_ERR_HIP with a message --
     in well under the time a hang would take -- and the engine serves the next batch normally."""
@@ -101,6 +107,7 @@ def test_lost_arrival_ends_in_an_error_not_a_hang(eng):
     clips = [synth.synth_waveform(90 + k, 1.0) for k in range(32)]
     eng.set_tuning("chain", 0)
     eng.set_tuning("qa", 1)
+    eng.set_tuning("qa_gran", gran)
     want = eng.transcribe_batch(clips, max_tokens=6, ignore_eos=True)
     eng.set_tuning("chain_fault", 1)
     try:
@@ -111,6 +118,7 @@ def test_lost_arrival_ends_in_an_error_not_a_hang(eng):
     finally:
         eng.set_tuning("chain_fault", 0)
     assert eng.transcribe_batch(clips, max_tokens=6, ignore_eos=True) == want
+    eng.set_tuning("qa_gran", 1)
 
 
 def test_qa_long_context_second_round():
@@ -126,7 +134,10 @@ def test_qa_long_context_second_round():
         e.set_tuning("qa", 0)
         want = e.transcribe_batch(clips, max_tokens=20, ignore_eos=True)
         e.set_tuning("qa", 1)
-        assert e.transcribe_batch(clips, max_tokens=20, ignore_eos=True) == want
+        for gran in (1, 0):
+            e.set_tuning("qa_gran", gran)
+            assert e.transcribe_batch(clips, max_tokens=20, ignore_eos=True) == want, gran
     finally:
+        e.set_tuning("qa_gran", 1)
         e.set_tuning("qa", 1)
         e.close()
