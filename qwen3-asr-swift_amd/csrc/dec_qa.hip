@@ -443,9 +443,10 @@ void decode_qa_launch(const DecQaArgs& a0, hipStream_t s) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(k), L_TOTAL);
         hipLaunchKernelGGL(k, dim3(256), dim3(CT), L_TOTAL, s, a);
     };
-    // 5 = by batch: more than 16 rows -> 3 (behind the staging), else 4 (in front of the weight tile): profiles/r04_ab_fused_layer.txt
-    const int early = tuning().qa_early == 5 ? (a.B > 16 ? 3 : 4) : tuning().qa_early, gate = tuning().qa_gate;
+    // 5 = by batch: 16 rows and more -> 3 (behind the staging), else 4 (in front of the weight tile): profiles/r04_ab_fused_layer.txt
     const bool gran = tuning().qa_gran != 0 && a.gran != nullptr;
+    const int early = tuning().qa_early == 5 ? (a.B >= 16 ? 3 : 4) : tuning().qa_early;
+    const int gate = tuning().qa_gate == 2 ? (gran ? 1 : 0) : tuning().qa_gate;
     if (!gran) a.gran = nullptr;
 #define QA_GO2(E_, G_, R_)                                                                                                      \
     do {                                                                                                                          \

@@ -23,7 +23,7 @@ struct Tuning {
                              // weight tile | 2 like 1 on waves 4..7 only | 3 once the wave's activation rows are staged | 4 in front of the weight tile |
                              // 5 (default) 3 above 16 batch rows, 4 up to 16
     int qa_gran = 1;         // dec_qa hand-off: 1 data-tagged 8-byte granules (the data is the flag) | 0 write-through rows + arrival counter + sc1 row loads
-    int qa_gate = 0;         // dec_qa: 1 waves 1..7 hold their remaining K / V requests until wave 0 has signalled the projection | 0 as soon as the sums are in
+    int qa_gate = 2;         // dec_qa: 1 waves 1..7 hold their remaining K / V requests until wave 0 has sent the projection off | 0 as soon as the sums are in | 2 = 1 with granules, 0 with the counter form
     int chain_fault = 0;     // TEST ONLY: 1 = one workgroup of the fused q|k|v + attention launch never signals, so the bounded waits give up and the step
                              // ends with QASR_ERR_HIP (tests/test_gpu_chain.py::test_lost_arrival_ends_in_an_error_not_a_hang)
     int chain_proto = 0;     // chain arrival counters: 0 sharded (add to one of 8, poll all 8) | 1 replicated (add to all 8, poll one)

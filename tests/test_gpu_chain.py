@@ -93,7 +93,7 @@ def test_qa_request_schedules_agree(eng):
                 assert [eng.transcribe_batch(clips[:b], max_tokens=6, ignore_eos=True) for b in (1, 32)] == want, (gran, early, gate)
     finally:
         eng.set_tuning("qa_early", 5)
-        eng.set_tuning("qa_gate", 0)
+        eng.set_tuning("qa_gate", 2)
         eng.set_tuning("qa_gran", 1)
         eng.set_tuning("qa", 1)
 
