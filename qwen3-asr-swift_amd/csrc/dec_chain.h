@@ -62,6 +62,11 @@ struct DecQaArgs {
     // tag = (ctr[CHAIN_SEQ_WORD] << 8) | (epoch + 1): the sequence word is bumped by whatever zeroes the counters in front of a step
     // (greedy_finalize_kernel, decode_chain_reset), so a tag never equals what an earlier step or layer left in the buffer
     unsigned long long* gran = nullptr;
+    // MLX affine-quantised checkpoints: the q|k|v matrix as its packed decode-step image (dec_quant.h QuantImg; 4 or 8 bits, bf16 scales) instead
+    // of wqkv_p; needs gran
+    const uint32_t* wq_qp = nullptr;
+    const void* wq_sb = nullptr;
+    int wq_bits = 0;
 };
 constexpr int QA_GRAN_ROW = 2048;                                   // granules per batch row (4096 projected values)
 constexpr size_t QA_GRAN_BYTES = (size_t)32 * QA_GRAN_ROW * 8;

@@ -23,6 +23,7 @@
 // every older load of its own -- which is why wave 0 holds nothing but its first K half (landed long before its drain) until the rows are in.
 #include "dec_chain_dev.h"
 #include "dec_rope.h"
+#include "dec_quant_dev.h"
 #include <mutex>
 
 namespace qasr {
@@ -39,6 +40,88 @@ __device__ __forceinline__ long qa_vfrag_index(int key, int d) {       // = vfra
     return (((long)kb * DT + (d >> 4)) * 64 + (d & 15) + 16 * g) * 8 + half * 4 + j;
 }
 
+// The projection on an MLX affine-quantised q|k|v matrix (WQ = 4 or 8 bits, group 64, bf16 scales): decode_gemvq_kernel's arithmetic (dec_quant.hip)
+// for ONE 16-row weight tile and NB batch tiles -- rows normalised on their way into LDS together with the f32 sums of each 64-column group of
+// the STAGED values, k-blocks interleaved over the 8 waves, per group two MFMAs from a zero accumulator (A = activations, B = the integer
+// fragment) then tot += scale * acc + bias' * xsum on the vector unit, cross-wave sums in the order wave 0 + 1 + ... + 7.  Same bits as that
+// kernel (tests/test_gpu_chain.py).  acc[p] is valid on wave 0: batch row 16 p + (lane >> 2), weight rows 4 (lane & 3) .. + 3 of the tile.
+template <int BITS, int NB, class Hook>
+__device__ __forceinline__ void qa_project_q(const uint4 (&wqr)[BITS == 4 ? 1 : 2], const float (&qsc)[BITS == 4 ? 1 : 2][BITS == 4 ? 2 : 1],
+                                             const float (&qbi)[BITS == 4 ? 1 : 2][BITS == 4 ? 2 : 1], const uint4 (&xr)[NB][4],
+                                             const char* s_normw, float eps, char* s_x, float* s_red, f32x4 (&acc)[1][NB], Hook after_stage) {
+    constexpr int K = CH_H, XSTRIDE = 2 * K + 16, KBW = BITS == 4 ? 1 : 2, GPB = BITS == 4 ? 2 : 1, TPR = 32, GH = K / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fc = lane >> 4;
+    const int srow = tid >> 5, scol = tid & 31;
+    float* s_xs = reinterpret_cast<float*>(s_x + (size_t)NB * 16 * XSTRIDE);            // [NB][GH][16]
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        char* xrow = s_x + (size_t)(p * 16 + srow) * XSTRIDE + scol * 16;
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[p][i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf16_to_f32(e[j]); ss = fmaf(f, f, ss); }
+        }
+        ss = lane_sum<TPR>(ss);
+        const float inv = rsqrtf(ss / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 nw = *reinterpret_cast<const uint4*>(s_normw + (scol + i * TPR) * 16);
+            uint4 o = xr[p][i];
+            o = make_uint4(rmsnorm_pair_bf16(o.x, nw.x, inv), rmsnorm_pair_bf16(o.y, nw.y, inv),
+                           rmsnorm_pair_bf16(o.z, nw.z, inv), rmsnorm_pair_bf16(o.w, nw.w, inv));
+            *reinterpret_cast<uint4*>(xrow + i * TPR * 16) = o;
+            const bf16_t* oe = reinterpret_cast<const bf16_t*>(&o);
+            float s8 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8 += bf16_to_f32(oe[j]);
+            s8 = lane_sum8(s8);
+            if ((scol & 7) == 0) s_xs[(p * GH + ((scol + TPR * i) >> 3)) * 16 + srow] = s8;
+        }
+    }
+    after_stage();
+    __syncthreads();
+    f32x4 tot[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) tot[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KBW; ++i) {
+        const int blk = wave + CWAVES * i;
+#pragma unroll
+        for (int h = 0; h < GPB; ++h) {
+            const int g = blk * GPB + h;
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const f32x4 xs = *reinterpret_cast<const f32x4*>(s_xs + (p * GH + g) * 16 + fc * 4);
+                const char* xb = s_x + (size_t)(p * 16 + fr) * XSTRIDE;
+                const uint4 x0 = *reinterpret_cast<const uint4*>(xb + ((g * 2 + 0) * 32 + fc * 8) * 2);
+                const uint4 x1 = *reinterpret_cast<const uint4*>(xb + ((g * 2 + 1) * 32 + fc * 8) * 2);
+                f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x0), frag_of<BITS>(wqr[i], 2 * h + 0), a2, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, x1), frag_of<BITS>(wqr[i], 2 * h + 1), a2, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tot[p][j] += qsc[i][h] * a2[j] + qbi[i][h] * xs[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_red[((size_t)(wave * NB + p) * 16 + fc * 4 + j) * 16 + fr] = tot[p][j];
+    __syncthreads();
+    if (wave == 0) {
+        const int erow = lane >> 2, eq = lane & 3;
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            acc[0][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wv = 0; wv < CWAVES; ++wv)
+                acc[0][p] += *reinterpret_cast<const f32x4*>(s_red + ((size_t)(wv * NB + p) * 16 + erow) * 16 + eq * 4);
+        }
+    }
+}
+
 // ST: diagnostic instantiation (qasr_kernel_probe 7), stamps of the 100 MHz clock in a.dbg[wg * 32 + i]: thread 0: 0 entry, 1 rows staged,
 // 2 projection summed, 3 signalled, 4 wait over, 7 output stored; thread 64 (wave 1): 5 own rows AND its K / V chunks in, 6 sweep done
 // EARLY: which waves request the K half of their first chunk before the projection: 0 none | 1 all | 2 waves 4..7 (A/B, knob qa_early).
@@ -47,8 +130,10 @@ __device__ __forceinline__ long qa_vfrag_index(int key, int d) {       // = vfra
 // GRAN: 1 = the hand-off as data-tagged granules (DecQaArgs::gran): wave 0 stores {two values, tag} words straight from the sums -- no drain, no
 //       counter -- and the consumer's wave 0 re-reads ITS 256 granules until every tag is this launch's: the poll and the rows' fetch are one
 //       round trip | 0 = write-through rows + one arrival counter per kv head + sc1 row loads (the first form; knob qa_gran).
-template <int NB, bool ST, int EARLY, int GATE, int GRAN>
+// WQ: 0 = bf16 weights (fragment-major image) | 4, 8 = MLX affine-quantised q|k|v matrix of that many bits (qa_project_q; granule hand-off only)
+template <int NB, bool ST, int EARLY, int GATE, int GRAN, int WQ = 0>
 __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
+    static_assert(WQ == 0 || (GRAN == 1 && !ST), "quantised projection: granule hand-off, no stamps");
     constexpr int HD = QA_HD, REP = 2, KS = HD / 32, DT = HD / 16, HALF = HD / 2, WAVES = CWAVES, UNR = QA_UNR;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4, fc = g;
@@ -80,9 +165,27 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         for (int i = 0; i < 4; ++i) xr[p][i] = *reinterpret_cast<const uint4*>(xp + i * 32 * 8);
     }
     uint4 wC[1][4];
+    constexpr int QKBW = WQ == 8 ? 2 : 1, QGPB = WQ == 8 ? 1 : 2, QBLK = WQ == 8 ? 64 : 128;      // k-blocks per wave, groups per block, columns per block
+    uint4 wqr[QKBW];
+    float qsc[QKBW][QGPB], qbi[QKBW][QGPB];
     auto request_w = [&]() {
+        if constexpr (WQ == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wC[0][i] = *reinterpret_cast<const uint4*>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
+            for (int i = 0; i < 4; ++i) wC[0][i] = *reinterpret_cast<const uint4*>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
+        } else {
+            // tile wg of the packed image: [tile][K / BLK blocks][64 lanes][16 B], scales / biases [tile][2][16 rows][K / 64 groups] (bf16)
+            const uint32_t* qp = a.wq_qp + ((long)wg * (CH_H / QBLK) * 64 + lane) * 4;
+#pragma unroll
+            for (int i = 0; i < QKBW; ++i) wqr[i] = *reinterpret_cast<const uint4*>(qp + (long)(wave + CWAVES * i) * 256);
+#pragma unroll
+            for (int i = 0; i < QKBW; ++i)
+#pragma unroll
+                for (int h = 0; h < QGPB; ++h) {
+                    const int grp = (wave + CWAVES * i) * QGPB + h;
+                    qsc[i][h] = sb_at<false>(a.wq_sb, (((long)wg * 2 + 0) * 16 + fr) * (CH_H / 64) + grp);
+                    qbi[i][h] = eff_bias<WQ == 8 ? 8 : 4>(qsc[i][h], sb_at<false>(a.wq_sb, (((long)wg * 2 + 1) * 16 + fr) * (CH_H / 64) + grp));
+                }
+        }
     };
     if constexpr (EARLY != 4) request_w();
 
@@ -133,7 +236,10 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     {
         f32x4 acc[1][NB];
         auto hook = [&]() { if constexpr (EARLY == 3) request_k(0); };
-        chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1, hook);
+        if constexpr (WQ == 0) chain_mma<1, NB, 4, true, ST>(wC, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, st + 1, hook);
+        else qa_project_q<WQ, NB>(wqr, qsc, qbi, xr, dsm + L_NORM, a.eps, s_x, s_red, acc, hook);
+        // a lane of wave 0 now holds four consecutive values of one batch row of the tile: row orow, values 4 ocol .. + 3
+        const int orow = WQ == 0 ? fr : lane >> 2, ocol = WQ == 0 ? fc : lane & 3;
         auto rest = [&]() { if (!early_wave) request_k(0); request_v(0); request_k(1); request_v(1); };
         if constexpr (!GATE) { if (wave != 0) rest(); }
         if (wave == 0) {
@@ -142,10 +248,10 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
                 if (!(a.fault && wg == 5)) {
 #pragma unroll
                     for (int p = 0; p < NB; ++p) {
-                        const int row = p * 16 + fr;
+                        const int row = p * 16 + orow;
                         if (row < B) {
                             const uint2 v = pack_bf16x4(make_float4(acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3]));
-                            unsigned long long* gp = a.gran + (long)row * QA_GRAN_ROW + wg * 8 + fc * 2;
+                            unsigned long long* gp = a.gran + (long)row * QA_GRAN_ROW + wg * 8 + ocol * 2;
                             __hip_atomic_store(gp, ((unsigned long long)tag << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(gp + 1, ((unsigned long long)tag << 32) | v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -447,6 +553,19 @@ void decode_qa_launch(const DecQaArgs& a0, hipStream_t s) {
     const bool gran = tuning().qa_gran != 0 && a.gran != nullptr;
     const int early = tuning().qa_early == 5 ? (a.B >= 16 ? 3 : 4) : tuning().qa_early;
     const int gate = tuning().qa_gate == 2 ? (gran ? 1 : 0) : tuning().qa_gate;
+    if (a.wq_bits) {
+        // quantised projection: the default schedule only (granules, gate, first K half behind the staging from 16 rows up, else in front of the weights)
+        if (!gran || (a.wq_bits != 4 && a.wq_bits != 8) || !a.wq_qp || !a.wq_sb) throw std::invalid_argument("decode qa: quantised projection needs granules and a 4 / 8-bit image");
+        const bool e3 = early == 3 || (early != 4 && a.B >= 16);
+#define QA_GOQ(W_)                                                                                                              \
+        do {                                                                                                                      \
+            if (e3) { if (a.B <= 16) go(decode_qa_kernel<1, false, 3, 1, 1, W_>); else go(decode_qa_kernel<2, false, 3, 1, 1, W_>); }  \
+            else { if (a.B <= 16) go(decode_qa_kernel<1, false, 4, 1, 1, W_>); else go(decode_qa_kernel<2, false, 4, 1, 1, W_>); }     \
+        } while (0)
+        if (a.wq_bits == 4) QA_GOQ(4); else QA_GOQ(8);
+#undef QA_GOQ
+        return;
+    }
     if (!gran) a.gran = nullptr;
 #define QA_GO2(E_, G_, R_)                                                                                                      \
     do {                                                                                                                          \

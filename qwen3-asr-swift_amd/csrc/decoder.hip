@@ -573,7 +573,11 @@ int Engine::step_chain(int r0, int nr) const {
 }
 bool Engine::step_qa(int r0, int nr, int chain) const {
     const int hd = cfg_.head_dim;
-    return !decw_.quant && r0 == 0 && !stamp_buf_ && !shared_device_ && chain < 3 && tuning().qa &&
+    if (decw_.quant) {      // quantised checkpoints: the packed image with bf16 scales, granule hand-off
+        const QuantImg& q = decw_.layers[0].qkv_q;
+        if (!q.qp || !q.sb || q.sb_f32 || (q.bits != 4 && q.bits != 8) || !tuning().qa_gran) return false;
+    }
+    return r0 == 0 && !stamp_buf_ && !shared_device_ && chain < 3 && tuning().qa &&
            decode_qa_supported(cfg_.hidden, cfg_.heads, cfg_.kv_heads, hd, nr, max_ctx_) && (cfg_.heads + 2 * cfg_.kv_heads) * hd == 4096;
 }
 void Engine::decode_structure(int* fused_qa, int* chain, int* launches_per_layer) {
@@ -623,6 +627,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
                         1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_,
                         (qa_dbg_ && l == cfg_.dec_layers / 2) ? qa_dbg_ : nullptr};
             q.gran = d_qa_gran_.as<unsigned long long>();
+            if (decw_.quant) { q.wq_qp = L.qkv_q.qp; q.wq_sb = L.qkv_q.sb; q.wq_bits = L.qkv_q.bits; }
             decode_qa_launch(q, s);
         } else {
             if (chain < 3 || l == 0) {         // chain 3: layer l's q|k|v came out of layer l - 1's launch
@@ -1025,6 +1030,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                 DecQaArgs q{d_dx_.as<bf16_t>(), Lq.ln1, Lq.wqkv_p, d_dqkv_.as<bf16_t>(), gstate_.ctx_len, Lq.qn, Lq.kn, rr.cos_rows, rr.sin_rows,
                             kvl, d_dattn_.as<bf16_t>(), rows, cfg_.rms_eps, 1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), 0u, d_err_flag_};
                 q.gran = d_qa_gran_.as<unsigned long long>();
+                if (decw_.quant) { q.wq_qp = Lq.qkv_q.qp; q.wq_sb = Lq.qkv_q.sb; q.wq_bits = Lq.qkv_q.bits; }
                 if (probe_ev) QASR_HIP(hipEventRecord(probe_ev[0], s));
                 decode_qa_launch(q, s);
                 if (probe_ev) QASR_HIP(hipEventRecord(probe_ev[1], s));

@@ -100,6 +100,12 @@ class Engine:
         self.check(self.lib.qasr_transcribe_batch(self.h, ptrs, ns, B, 16000, C.byref(o), iptr(toks), iptr(lens)))
         return [toks[b, :lens[b]].tolist() for b in range(B)]
 
+    def decode_structure(self):
+        """(fused q|k|v + attention launch?, chain mode, dependent launches per decoder layer) of the prepared batch's decode step."""
+        f, c, n = C.c_int(), C.c_int(), C.c_int()
+        self.check(self.lib.qasr_decode_structure(self.h, C.byref(f), C.byref(c), C.byref(n)))
+        return f.value, c.value, n.value
+
     def timings(self):
         ms = (C.c_float * 5)()
         steps = C.c_int32()

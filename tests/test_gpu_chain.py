@@ -141,3 +141,32 @@ def test_qa_long_context_second_round():
         e.set_tuning("qa_gran", 1)
         e.set_tuning("qa", 1)
         e.close()
+
+
+@pytest.mark.parametrize("bits", [4, 8], ids=["w4", "w8"])
+def test_qa_on_quantised_checkpoints_equals_the_two_launches(bits):
+    """MLX affine-quantised decoder (the reference's shipped format, QuantizedTextDecoder.swift:33-44): the fused launch projects with the packed
+    q|k|v image (dec_qa.hip qa_project_q = decode_gemvq_kernel's arithmetic, tile for tile) -- logits of forced steps and tokens at every batch
+    tile shape bit-equal to the q|k|v GEMV + attention launches."""
+    t = dataclasses.replace(C.TEXT_SMALL, layers=3)
+    sd = synth.synth_state_dict(dataclasses.replace(C.AUDIO_SMALL, layers=1), t, seed=3, init="stress")
+    e = gpu_util.Engine("0.6B", max_batch=32, max_audio_seconds=4, max_new_tokens=16, enc_layers=1, dec_layers=3, bits=bits)
+    try:
+        e.load_state_dict(synth.quantize_state_dict(sd, bits))
+        emb = P.bf16_round(torch.randn(33, 1024, generator=torch.Generator().manual_seed(9)) * 0.5).numpy()
+        clips = [synth.synth_waveform(k, 1.0 + 0.17 * (k % 5)) for k in range(32)]
+        e.set_tuning("qa", 0)
+        base = _run(e, clips, emb, [11, 151643, 5, 9000, 77])
+        assert len({tuple(t) for t in base[2][-1]}) > 1
+        e.set_tuning("qa", 1)
+        assert e.decode_structure()[0] == 1                   # the fused launch is what runs
+        for early in (5, 3, 4):
+            e.set_tuning("qa_early", early)
+            got = _run(e, clips, emb, [11, 151643, 5, 9000, 77])
+            assert np.array_equal(got[0], base[0]), early
+            assert np.array_equal(got[1], base[1]), (early, float(np.abs(got[1] - base[1]).max()))
+            assert got[2] == base[2], early
+    finally:
+        e.set_tuning("qa_early", 5)
+        e.set_tuning("qa", 1)
+        e.close()
