@@ -451,11 +451,14 @@ def main():
         d4 = run_leg(m4, clips, n_dec, args.steps, 1, 1, None, inclusive=True, pipelined=True)
         ms4, st4 = m4.batch_timings()
         p4 = {name: m4.kernel_probe(which, 20) for which, name in ((0, "layer_gemv"), (2, "lm_head"))}
+        fq4, ch4, lpl4 = m4.decode_structure()
         out["mlx_4bit"] = {"value": round(B * args.seconds * args.steps / d4, 1), "ms_per_step": round(d4 / args.steps * 1e3, 3),
                            "stage_ms": {"mel": round(ms4[0], 3), "encoder": round(ms4[1], 3), "prompt_pass": round(ms4[2], 3),
                                         "decode": round(ms4[3], 3), "decode_steps": st4},
                            "stage_roofline_decode": stage_roofline(B, args.seconds, n_dec, ms4, st4, 4).get("decode"),
                            "kernels": {k: {"avg_ms": round(v[0], 5), "bytes": v[1], "GBps": round(v[1] / v[0] / 1e6, 1)} for k, v in p4.items()},
+                           "decode_structure": {"fused_qkv_attention": bool(fq4), "dependent_launches_per_layer": lpl4,
+                                                "layer_gemv_covers": "o-proj + gate|up + down" if fq4 else "q|k|v + o-proj + gate|up + down"},
                            "note": "synthetic weights quantised with mlx's affine scheme (group 64); decode-step products in the "
                                    "reference's f32-dequantised form, prompt pass on bf16(scale*q+bias) like its many-row kernel"}
         m4.close()
