@@ -173,18 +173,16 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wC[0][i] = *reinterpret_cast<const uint4*>(a.wqkv_p + ((long)wg * (CH_H / 32) + wave + CWAVES * i) * 512 + lane * 8);
         } else {
-            // tile wg of the packed image: [tile][K / BLK blocks][64 lanes][16 B], scales / biases [tile][2][16 rows][K / 64 groups] (bf16)
+            // tile wg of the packed image: [tile][K / BLK blocks][64 lanes][16 B], scales / biases [tile][16 rows][K / 64 groups][2] (bf16)
             const uint32_t* qp = a.wq_qp + ((long)wg * (CH_H / QBLK) * 64 + lane) * 4;
 #pragma unroll
             for (int i = 0; i < QKBW; ++i) wqr[i] = *reinterpret_cast<const uint4*>(qp + (long)(wave + CWAVES * i) * 256);
 #pragma unroll
-            for (int i = 0; i < QKBW; ++i)
+            for (int i = 0; i < QKBW; ++i) {
+                sb_load<false, QGPB>(a.wq_sb, (((long)wg * 16 + fr) * (CH_H / 64) + (wave + CWAVES * i) * QGPB) * 2, qsc[i], qbi[i]);
 #pragma unroll
-                for (int h = 0; h < QGPB; ++h) {
-                    const int grp = (wave + CWAVES * i) * QGPB + h;
-                    qsc[i][h] = sb_at<false>(a.wq_sb, (((long)wg * 2 + 0) * 16 + fr) * (CH_H / 64) + grp);
-                    qbi[i][h] = eff_bias<WQ == 8 ? 8 : 4>(qsc[i][h], sb_at<false>(a.wq_sb, (((long)wg * 2 + 1) * 16 + fr) * (CH_H / 64) + grp));
-                }
+                for (int h = 0; h < QGPB; ++h) qbi[i][h] = eff_bias<WQ == 8 ? 8 : 4>(qsc[i][h], qbi[i][h]);
+            }
         }
     };
     if constexpr (EARLY != 4) request_w();

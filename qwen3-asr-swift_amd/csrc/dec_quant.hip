@@ -58,14 +58,14 @@ __global__ void quant_pack_q_kernel(const uint32_t* __restrict__ src, uint32_t* 
     reinterpret_cast<uint4*>(dst)[idx] = o;
 }
 
-// sb image [tile][which][row 16][g]: element size esz, plain copy with the tile interleave
+// sb image [tile][row 16][g][which = scale, bias]: element size esz (dec_quant_dev.h sb_load)
 __global__ void quant_pack_sb_kernel(const char* __restrict__ scales, const char* __restrict__ biases, char* __restrict__ dst,
                                      int N, int G, int esz) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;           // one element of scales AND of biases
     if (idx >= (long)N * G) return;
     const long row = idx / G, tile = row >> 4;
     const int g = (int)(idx - row * G), r = (int)(row & 15);
-    const long d0 = ((tile * 2 + 0) * 16 + r) * G + g, d1 = ((tile * 2 + 1) * 16 + r) * G + g;
+    const long d0 = ((tile * 16 + r) * G + g) * 2, d1 = d0 + 1;
     for (int b = 0; b < esz; ++b) { dst[d0 * esz + b] = scales[idx * esz + b]; dst[d1 * esz + b] = biases[idx * esz + b]; }
 }
 
@@ -244,12 +244,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
         for (int kp = 0; kp < KPH; ++kp)
 #pragma unroll
             for (int i = 0; i < KBW; ++i)
+            {
+                const int g = (kp * (KH / BLK) + wave + WAVES * i) * GPB;
+                sb_load<SBF32, GPB>(a2.sb, ((tile * 16 + fr) * G + g) * 2, sc[t][kp * KBW + i], bi[t][kp * KBW + i]);
 #pragma unroll
-                for (int h = 0; h < GPB; ++h) {
-                    const int g = (kp * (KH / BLK) + wave + WAVES * i) * GPB + h;
-                    sc[t][kp * KBW + i][h] = sb_at<SBF32>(a2.sb, ((tile * 2 + 0) * 16 + fr) * G + g);
-                    bi[t][kp * KBW + i][h] = eff_bias<BITS>(sc[t][kp * KBW + i][h], sb_at<SBF32>(a2.sb, ((tile * 2 + 1) * 16 + fr) * G + g));
-                }
+                for (int h = 0; h < GPB; ++h) bi[t][kp * KBW + i][h] = eff_bias<BITS>(sc[t][kp * KBW + i][h], bi[t][kp * KBW + i][h]);
+            }
     }
     // the later phases' activation rows: behind the weight requests, in registers long before their phase
 #pragma unroll
@@ -551,11 +551,9 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
         const long tile = gw + (long)(bi_seq / NBLK) * total_waves;
         const int kb = bi_seq % NBLK;
         q = *reinterpret_cast<const uint4*>(a.qp + ((tile * NBLK + kb) * 64 + lane) * 4);
+        sb_load<SBF32, GPB>(a.sb, ((tile * 16 + fr) * G + kb * GPB) * 2, sc, bi);
 #pragma unroll
-        for (int h = 0; h < GPB; ++h) {
-            sc[h] = sb_at<SBF32>(a.sb, ((tile * 2 + 0) * 16 + fr) * G + kb * GPB + h);
-            bi[h] = eff_bias<BITS>(sc[h], sb_at<SBF32>(a.sb, ((tile * 2 + 1) * 16 + fr) * G + kb * GPB + h));
-        }
+        for (int h = 0; h < GPB; ++h) bi[h] = eff_bias<BITS>(sc[h], bi[h]);
     };
     // LDS-ring form: request block `seq` of this wave's sequence into slot seq % LR (a dummy block past the end)
     const int nseq = my_tiles * PT;
@@ -653,11 +651,9 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
                     wf[2 * h + 1] = frag_of<BITS>(blk, 2 * h + 1);
                 }
                 float sg[GPB], bg[GPB];
+                sb_load<SBF32, GPB>(sbcur, ((long)fr * G + kb * GPB) * 2, sg, bg);
 #pragma unroll
-                for (int h = 0; h < GPB; ++h) {
-                    sg[h] = sb_at<SBF32>(sbcur, (0 * 16 + fr) * G + kb * GPB + h);
-                    bg[h] = eff_bias<BITS>(sg[h], sb_at<SBF32>(sbcur, (1 * 16 + fr) * G + kb * GPB + h));
-                }
+                for (int h = 0; h < GPB; ++h) bg[h] = eff_bias<BITS>(sg[h], bg[h]);
                 __builtin_amdgcn_sched_barrier(0);
                 issue(seq + LR);                                // blk is in registers (the fragment conversion consumed it)
                 const char* xw = s_x + (size_t)fr * XSTRIDE + fc * 16 + (size_t)kb * GPB * 128;

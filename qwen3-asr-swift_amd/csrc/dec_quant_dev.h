@@ -12,6 +12,33 @@ __device__ __forceinline__ float sb_at(const void* p, long i) {
     else return bf16_to_f32(reinterpret_cast<const bf16_t*>(p)[i]);
 }
 
+// Scale / bias image of a matrix (quant_pack_sb_kernel): per 16-row tile [row 16][group G][2 = scale, bias], so that the GPB consecutive groups
+// of one k-block of one weight row are ONE aligned load of 2 GPB elements (4 - 16 bytes) instead of 2 GPB scalar ones -- a wave-level load
+// instruction costs the CU's address path the same ~16 clocks whether it fetches 2 or 16 bytes per lane, and the decode GEMVs issued up to 16 of
+// the 2-byte kind per lane behind their weights.  first = element index of the first group's scale: ((tile * 16 + row) * G + g) * 2.
+template <bool F32, int GPB>
+__device__ __forceinline__ void sb_load(const void* img, long first, float (&sc)[GPB], float (&bi)[GPB]) {
+    static_assert(GPB == 1 || GPB == 2, "groups per k-block");
+    if constexpr (F32) {
+        if constexpr (GPB == 2) {
+            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(img) + first);
+            sc[0] = __uint_as_float(v.x); bi[0] = __uint_as_float(v.y); sc[1] = __uint_as_float(v.z); bi[1] = __uint_as_float(v.w);
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(img) + first);
+            sc[0] = __uint_as_float(v.x); bi[0] = __uint_as_float(v.y);
+        }
+    } else {
+        if constexpr (GPB == 2) {
+            const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(img) + first);
+            sc[0] = __uint_as_float(v.x << 16); bi[0] = __uint_as_float(v.x & 0xffff0000u);
+            sc[1] = __uint_as_float(v.y << 16); bi[1] = __uint_as_float(v.y & 0xffff0000u);
+        } else {
+            const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(img) + first);
+            sc[0] = __uint_as_float(v << 16); bi[0] = __uint_as_float(v & 0xffff0000u);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // q (integers < 2^bits) -> bf16 MFMA fragment, exactly: v_cvt_f32_ubyteN then a truncating pack (an integer < 256 has at
 // most 8 significant bits, so its f32 image already is a bf16 value).
