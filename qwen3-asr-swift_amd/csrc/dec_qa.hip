@@ -123,7 +123,8 @@ __device__ __forceinline__ void qa_project_q(const uint4 (&wqr)[BITS == 4 ? 1 : 
 }
 
 // ST: diagnostic instantiation (qasr_kernel_probe 7), stamps of the 100 MHz clock in a.dbg[wg * 32 + i]: thread 0: 0 entry, 1 rows staged,
-// 2 projection summed, 3 signalled, 4 wait over, 7 output stored; thread 64 (wave 1): 5 own rows AND its K / V chunks in, 6 sweep done
+// 2 projection summed, 3 signalled, 4 wait over, 7 output stored, 8 query prepared; thread 64 (wave 1): 9 its own K / V chunks in, 5 the barrier
+// behind the preparation passed (= every wave's requests have landed: __syncthreads drains them), 6 sweep done
 // EARLY: which waves request the K half of their first chunk before the projection: 0 none | 1 all | 2 waves 4..7 (A/B, knob qa_early).
 // GATE: 1 = waves 1..7 hold their remaining requests until wave 0 has stored, drained and signalled the projection (so that the hand-off's
 //       write-through stores are not queued behind the stream) | 0 = they request as soon as the sums are in (knob qa_gate).
@@ -407,7 +408,9 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             s_vn[i] = bf16_to_f32(vown[ii]);
             dvf[qa_vfrag_index<HD>(pos, i)] = vown[ii];
         }
+        QA_STAMP(8, 0);                                                // wave 0: query prepared, k / v appended
     }
+    if constexpr (ST) { if (wave == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[9] = wall_clock64(); } }     // wave 1: its two chunks are in (all lanes write the same word)
     __syncthreads();
     if constexpr (GRAN) { if (*s_flag == 0) return; }                 // the sweep gave up (uniform: read behind the barrier)
     if constexpr (ST) { if (wave == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -1157,7 +1157,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
         d.alloc(n * sizeof(unsigned long long));
         std::vector<unsigned long long> hst(n);
         static const char* qnames[19] = {"entry", "rows staged", "proj summed", "signalled", "wait over", "w1 rows+K/V in", "w1 sweep done", "stored",
-                                         "", "", "", "", "", "", "", "", "", "", ""};
+                                         "w0 query ready", "w1 own K/V in", "", "", "", "", "", "", "", "", ""};
         static const char* cnames[19] = {"entry", "O staged", "O summed", "O signalled", "GU wait over", "GU rows in", "GU staged", "GU summed",
                                         "GU signalled", "DOWN wait over", "DOWN rows in", "DOWN staged", "DOWN summed", "DOWN signalled",
                                         "QKV wait over", "QKV rows in", "QKV staged", "QKV summed", "QKV stored"};
