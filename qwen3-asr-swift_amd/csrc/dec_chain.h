@@ -64,10 +64,15 @@ struct DecQaArgs {
     unsigned long long* gran = nullptr;
     // MLX affine-quantised checkpoints: the q|k|v matrix as its packed decode-step image (dec_quant.h QuantImg; 4 or 8 bits, bf16 scales) instead
     // of wqkv_p; needs gran
+    // up to 16 batch rows: an attention unit spread over 2 / 4 / 8 workgroups (knob qa_split); their per-wave partials travel here,
+    // [unit][8 waves][QA_PART_STRIDE] granules, same tags
+    unsigned long long* part = nullptr;
     const uint32_t* wq_qp = nullptr;
     const void* wq_sb = nullptr;
     int wq_bits = 0;
 };
+constexpr int QA_PART_STRIDE = 264;                                // 2 x 128 outputs + 2 maxima + 2 sums, padded to whole 64-byte blocks
+constexpr size_t QA_PART_BYTES = (size_t)128 * 8 * QA_PART_STRIDE * 8;   // 16 rows x 8 kv heads = 128 units
 constexpr int QA_GRAN_ROW = 2048;                                   // granules per batch row (4096 projected values)
 constexpr size_t QA_GRAN_BYTES = (size_t)32 * QA_GRAN_ROW * 8;
 bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_ctx);

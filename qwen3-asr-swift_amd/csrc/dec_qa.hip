@@ -132,17 +132,25 @@ __device__ __forceinline__ void qa_project_q(const uint4 (&wqr)[BITS == 4 ? 1 : 
 //       counter -- and the consumer's wave 0 re-reads ITS 256 granules until every tag is this launch's: the poll and the rows' fetch are one
 //       round trip | 0 = write-through rows + one arrival counter per kv head + sc1 row loads (the first form; knob qa_gran).
 // WQ: 0 = bf16 weights (fragment-major image) | 4, 8 = MLX affine-quantised q|k|v matrix of that many bits (qa_project_q; granule hand-off only)
-template <int NB, bool ST, int EARLY, int GATE, int GRAN, int WQ = 0>
+// SPLIT (up to 16 batch rows, where the 8 x B attention units leave most CUs without one and a unit's K / V rows -- 240 KB at 30 s -- come through ONE
+//       CU's request path): a unit is spread over SPLIT = 2, 4 or 8 workgroups.  Workgroup (unit, s) sweeps the chunks that waves w = s (mod SPLIT) swept
+//       before -- wave w keeps its chunk set and its running (max, sum, output), so the eight per-wave partials are the SAME numbers -- and the workgroups
+//       s != 0 hand theirs to workgroup (unit, 0) as tagged granules (DecQaArgs::part); there the waves without chunks poll one partner each into the
+//       LDS slots the merge reads: same merge, same order, same bits.
+template <int NB, bool ST, int EARLY, int GATE, int GRAN, int WQ = 0, int SPLIT = 1>
 __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     static_assert(WQ == 0 || (GRAN == 1 && !ST), "quantised projection: granule hand-off, no stamps");
+    static_assert(SPLIT == 1 || ((SPLIT == 2 || SPLIT == 4 || SPLIT == 8) && GRAN == 1 && NB == 1 && !ST), "context split: granules, one batch tile");
     constexpr int HD = QA_HD, REP = 2, KS = HD / 32, DT = HD / 16, HALF = HD / 2, WAVES = CWAVES, UNR = QA_UNR;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4, fc = g;
     const int srow = tid >> 5, scol = tid & 31;
     const int wg = blockIdx.x;
     const int B = a.B;
-    const int b = wg >> 3, kvh = wg & 7;
+    const int unit = wg / SPLIT, sp = wg % SPLIT;
+    const int b = unit >> 3, kvh = unit & 7;
     const bool has_att = b < B;
+    const bool has_work = SPLIT == 1 || (wave % SPLIT) == sp;          // this wave sweeps chunks in this workgroup
     const int bq = has_att ? b : 0;
     char* s_x = dsm + L_X;
     float* s_red = reinterpret_cast<float*>(dsm + L_RED);
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         ch = ch < nchunks - 1 ? ch : nchunks - 1;                     // chunks past the context re-read the last one (cache hits), skipped in the sweep
         ch_early[u] = ch < max_chunk ? ch : max_chunk;
     }
+    const bool live = has_att && has_work;                            // waves without chunks request one cached line instead
     // unconditional request code (addresses selected, not branches), so that hipcc's counted waits for the projection's operands stay exact
     auto request_k = [&](int u) {
         const bf16_t* kr = kb + ((long)ch_early[u] * 32 + fr) * HD;
@@ -209,12 +218,12 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(has_att ? kr + (long)h * 16 * HD + ks * 32 : kdummy);
+                kreg[u][h * KS + ks] = *reinterpret_cast<const uint4*>(live ? kr + (long)h * 16 * HD + ks * 32 : kdummy);
     };
     auto request_v = [&](int u) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            vreg[u][dt] = *reinterpret_cast<const uint4*>(has_att ? vfb + ((long)ch_early[u] * DT + dt) * 512 : kdummy);
+            vreg[u][dt] = *reinterpret_cast<const uint4*>(live ? vfb + ((long)ch_early[u] * DT + dt) * 512 : kdummy);
     };
     // (wave 0 may take part: its 8 requests have landed long before its drain)
     // EARLY 3: the same request from every wave once its activation rows have left for LDS (chain_mma's after-stage hook); 4: before the
@@ -359,17 +368,17 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) kreg[0][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+                    for (int ks = 0; ks < KS; ++ks) kreg[0][h * KS + ks] = *reinterpret_cast<const uint4*>(live ? kr + (long)h * 16 * HD + ks * 32 : kdummy);
             }
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vreg[0][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[0] * DT + dt) * 512);
+            for (int dt = 0; dt < DT; ++dt) vreg[0][dt] = *reinterpret_cast<const uint4*>(live ? vfb + ((long)ch_early[0] * DT + dt) * 512 : kdummy);
             const bf16_t* kr = kb + ((long)ch_early[1] * 32 + fr) * HD;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kreg[1][h * KS + ks] = *reinterpret_cast<const uint4*>(kr + (long)h * 16 * HD + ks * 32);
+                for (int ks = 0; ks < KS; ++ks) kreg[1][h * KS + ks] = *reinterpret_cast<const uint4*>(live ? kr + (long)h * 16 * HD + ks * 32 : kdummy);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vreg[1][dt] = *reinterpret_cast<const uint4*>(vfb + ((long)ch_early[1] * DT + dt) * 512);
+            for (int dt = 0; dt < DT; ++dt) vreg[1][dt] = *reinterpret_cast<const uint4*>(live ? vfb + ((long)ch_early[1] * DT + dt) * 512 : kdummy);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float w1 = bf16_to_f32(w1r), w2 = bf16_to_f32(w2r), kw1 = bf16_to_f32(kw1r), kw2 = bf16_to_f32(kw2r);
@@ -390,23 +399,25 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             s_q[r * HD + lane] = f32_to_bf16(qa[r][0]);
             s_q[r * HD + lane + HALF] = f32_to_bf16(qa[r][1]);
         }
-        const float inv = rsqrtf(lane_sum<64>(kx1 * kx1 + kx2 * kx2) / (float)HD + a.eps);
-        float k1, k2;
-        norm_rope_pair(kx1, kx2, kw1, kw2, inv, rc, rs, k1, k2);
-        bf16_t* dk = cache.k + cache.off(b, kvh, pos);
-        dk[lane] = f32_to_bf16(k1);
-        dk[lane + HALF] = f32_to_bf16(k2);
+        if (SPLIT == 1 || sp == 0) {       // the token's own k / v: appended once per unit, its score and value enter the merge there
+            const float inv = rsqrtf(lane_sum<64>(kx1 * kx1 + kx2 * kx2) / (float)HD + a.eps);
+            float k1, k2;
+            norm_rope_pair(kx1, kx2, kw1, kw2, inv, rc, rs, k1, k2);
+            bf16_t* dk = cache.k + cache.off(b, kvh, pos);
+            dk[lane] = f32_to_bf16(k1);
+            dk[lane + HALF] = f32_to_bf16(k2);
 #pragma unroll
-        for (int r = 0; r < REP; ++r) {
-            const float d = lane_sum<64>(qa[r][0] * k1 + qa[r][1] * k2);
-            if (lane == 0) s_new[r] = d * a.scale;
-        }
-        bf16_t* dvf = cache.vf + cache.off(b, kvh, 0);
+            for (int r = 0; r < REP; ++r) {
+                const float d = lane_sum<64>(qa[r][0] * k1 + qa[r][1] * k2);
+                if (lane == 0) s_new[r] = d * a.scale;
+            }
+            bf16_t* dvf = cache.vf + cache.off(b, kvh, 0);
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int i = lane + 64 * ii;
-            s_vn[i] = bf16_to_f32(vown[ii]);
-            dvf[qa_vfrag_index<HD>(pos, i)] = vown[ii];
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = lane + 64 * ii;
+                s_vn[i] = bf16_to_f32(vown[ii]);
+                dvf[qa_vfrag_index<HD>(pos, i)] = vown[ii];
+            }
         }
         QA_STAMP(8, 0);                                                // wave 0: query prepared, k / v appended
     }
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.0f;
     const float scale = a.scale;
-    for (int c0 = wave; c0 < nchunks; c0 += WAVES * UNR) {
+    for (int c0 = has_work ? wave : nchunks; c0 < nchunks; c0 += WAVES * UNR) {
         if (c0 != wave) issue(c0, nchunks);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -494,12 +505,66 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
     }
     QA_STAMP(6, 64);
     l_run = rows4_sum(l_run);
-    if (lane < REP) { s_m[wave * REP + lane] = m_run; s_l[wave * REP + lane] = l_run; }
-    if (g == 0) {
+    if constexpr (SPLIT > 1) {
+        // partial of wave w of unit u: QA_PART_STRIDE granules -- [r * HD + d] the outputs, [REP * HD + r] the running maxima, [REP * HD + REP + r] the sums
+        unsigned long long* pw = a.part + ((long)unit * WAVES + wave) * QA_PART_STRIDE;
+        const unsigned long long tg = (unsigned long long)tag << 32;
+        if (sp != 0) {
+            if (has_work) {
+                if (lane < REP) {
+                    __hip_atomic_store(pw + REP * HD + lane, tg | __float_as_uint(m_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pw + REP * HD + REP + lane, tg | __float_as_uint(l_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (g == 0) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            s_o[(wave * REP + 0) * HD + dt * 16 + fr] = o[dt][0];
-            s_o[(wave * REP + 1) * HD + dt * 16 + fr] = o[dt][1];
+                    for (int dt = 0; dt < DT; ++dt) {
+                        __hip_atomic_store(pw + 0 * HD + dt * 16 + fr, tg | __float_as_uint(o[dt][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pw + 1 * HD + dt * 16 + fr, tg | __float_as_uint(o[dt][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            return;                         // (every wave of this workgroup: sp is uniform)
+        }
+        if (!has_work) {
+            // workgroup (unit, 0), a wave without chunks: fetch the partial that wave `wave` of workgroup (unit, wave % SPLIT) sends, into the slots the
+            // merge reads.  Bounded like every in-launch wait; on a give-up the slot gets an empty partial and the step ends in QASR_ERR_HIP.
+            constexpr int NG = REP * HD + 2 * REP, NL = (NG + 63) / 64;
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long x[NL];
+            bool ok;
+            for (;;) {
+                bool mine = true;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const int idx = lane + 64 * i;
+                    x[i] = idx < NG ? __hip_atomic_load(pw + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tg;
+                    mine &= (unsigned)(x[i] >> 32) == tag;
+                }
+                const unsigned e = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.err), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool dead = (e & CHAIN_ERR_TIMEOUT) != 0;
+                ok = !dead && __builtin_amdgcn_ballot_w64(!mine) == 0;
+                if (ok || dead || wall_clock64() - t0 > CH_SPIN_TICKS) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && lane == 0) atomicOr(a.err, CHAIN_ERR_TIMEOUT);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = lane + 64 * i;
+                const float v = __uint_as_float((unsigned)x[i]);
+                if (idx < REP * HD) s_o[wave * REP * HD + idx] = ok ? v : 0.0f;
+                else if (idx < REP * HD + REP) s_m[wave * REP + idx - REP * HD] = ok ? v : -INFINITY;
+                else if (idx < NG) s_l[wave * REP + idx - REP * HD - REP] = ok ? v : 0.0f;
+            }
+        }
+    }
+    if (has_work) {
+        if (lane < REP) { s_m[wave * REP + lane] = m_run; s_l[wave * REP + lane] = l_run; }
+        if (g == 0) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                s_o[(wave * REP + 0) * HD + dt * 16 + fr] = o[dt][0];
+                s_o[(wave * REP + 1) * HD + dt * 16 + fr] = o[dt][1];
+            }
         }
     }
     __syncthreads();
@@ -554,6 +619,20 @@ void decode_qa_launch(const DecQaArgs& a0, hipStream_t s) {
     const bool gran = tuning().qa_gran != 0 && a.gran != nullptr;
     const int early = tuning().qa_early == 5 ? (a.B >= 16 ? 3 : 4) : tuning().qa_early;
     const int gate = tuning().qa_gate == 2 ? (gran ? 1 : 0) : tuning().qa_gate;
+    // up to 8 rows: a unit's context over 8 / 4 workgroups (default schedule only: granules, gate, first K half by batch); measured -4.4 % decode at 1 row,
+    // -3.5 % at 4, -1.4 % at 8, +0.2 % at 16 with two workgroups per unit (profiles/r04_ab_fused_layer.txt); qa_split 2 forces the split up to 16 rows
+    int split = 1;
+    if (tuning().qa_split && gran && a.part && a.B <= (tuning().qa_split == 2 ? 16 : 8) && gate == 1 && (early == 3 || early == 4))
+        split = a.B <= 4 ? 8 : a.B <= 8 ? 4 : 2;
+    if (split > 1) {
+        if (a.wq_bits && ((a.wq_bits != 4 && a.wq_bits != 8) || !a.wq_qp || !a.wq_sb)) throw std::invalid_argument("decode qa: 4 / 8-bit image expected");
+#define QA_GOS(W_, S_) do { if (early == 3) go(decode_qa_kernel<1, false, 3, 1, 1, W_, S_>); else go(decode_qa_kernel<1, false, 4, 1, 1, W_, S_>); } while (0)
+#define QA_GOSW(S_) do { if (a.wq_bits == 4) QA_GOS(4, S_); else if (a.wq_bits == 8) QA_GOS(8, S_); else QA_GOS(0, S_); } while (0)
+        if (split == 8) QA_GOSW(8); else if (split == 4) QA_GOSW(4); else QA_GOSW(2);
+#undef QA_GOSW
+#undef QA_GOS
+        return;
+    }
     if (a.wq_bits) {
         // quantised projection: the default schedule only (granules, gate, first K half behind the staging from 16 rows up, else in front of the weights)
         if (!gran || (a.wq_bits != 4 && a.wq_bits != 8) || !a.wq_qp || !a.wq_sb) throw std::invalid_argument("decode qa: quantised projection needs granules and a 4 / 8-bit image");

@@ -274,6 +274,8 @@ void Engine::finalize_decoder() {
     QASR_HIP(hipMemsetAsync(d_chain_ctr_.p, 0, CHAIN_STATE_BYTES, stream_));
     d_qa_gran_.alloc(QA_GRAN_BYTES);
     QASR_HIP(hipMemsetAsync(d_qa_gran_.p, 0, QA_GRAN_BYTES, stream_));
+    d_qa_part_.alloc(QA_PART_BYTES);
+    QASR_HIP(hipMemsetAsync(d_qa_part_.p, 0, QA_PART_BYTES, stream_));
     d_logits_.alloc((size_t)B * cfg_.vocab * sizeof(float));
     n_parts_ = decw_.quant ? lm_head_q_parts(cfg_.vocab, H, cfg_.bits) : lm_head_parts(cfg_.vocab, H);
     const int parts_cap = std::max(n_parts_, decode_gemv_blocks(DEC_EPI_LOGITS, cfg_.vocab));
@@ -627,6 +629,7 @@ void Engine::run_decode_step(bool want_logits, bool greedy, int r0, int nr, hipS
                         1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), (unsigned)l, d_err_flag_,
                         (qa_dbg_ && l == cfg_.dec_layers / 2) ? qa_dbg_ : nullptr};
             q.gran = d_qa_gran_.as<unsigned long long>();
+            q.part = d_qa_part_.as<unsigned long long>();
             if (decw_.quant) { q.wq_qp = L.qkv_q.qp; q.wq_sb = L.qkv_q.sb; q.wq_bits = L.qkv_q.bits; }
             decode_qa_launch(q, s);
         } else {
@@ -1030,6 +1033,7 @@ void Engine::kernel_probe(int which, int reps, float* avg_ms, double* bytes_per_
                 DecQaArgs q{d_dx_.as<bf16_t>(), Lq.ln1, Lq.wqkv_p, d_dqkv_.as<bf16_t>(), gstate_.ctx_len, Lq.qn, Lq.kn, rr.cos_rows, rr.sin_rows,
                             kvl, d_dattn_.as<bf16_t>(), rows, cfg_.rms_eps, 1.0f / sqrtf((float)hd), d_chain_ctr_.as<unsigned>(), 0u, d_err_flag_};
                 q.gran = d_qa_gran_.as<unsigned long long>();
+                q.part = d_qa_part_.as<unsigned long long>();
                 if (decw_.quant) { q.wq_qp = Lq.qkv_q.qp; q.wq_sb = Lq.qkv_q.sb; q.wq_bits = Lq.qkv_q.bits; }
                 if (probe_ev) QASR_HIP(hipEventRecord(probe_ev[0], s));
                 decode_qa_launch(q, s);

@@ -263,6 +263,7 @@ private:
     bool shared_device_ = false;
     unsigned long long* qa_dbg_ = nullptr;
     unsigned long long* chain_dbg_ = nullptr;                  // diagnostic stamps of the middle layer's chain launch (kernel_probe 6)
+    DevBuf d_qa_part_;                                         // ... and the per-wave attention partials of a unit spread over several workgroups (QA_PART_BYTES)
     DevBuf d_qa_gran_;                                         // the fused q|k|v + attention launch's hand-off granules (dec_chain.h QA_GRAN_BYTES)
     DevBuf d_chain_ctr_;                                       // arrival counters of the persistent layer launch (dec_chain.h)
     HostBuf h_pmeta_;

@@ -170,3 +170,23 @@ def test_qa_on_quantised_checkpoints_equals_the_two_launches(bits):
         e.set_tuning("qa_early", 5)
         e.set_tuning("qa", 1)
         e.close()
+
+
+def test_qa_context_split_at_small_batches(eng):
+    """Up to 8 (knob qa_split 2: 16) batch rows an attention unit is spread over 8 / 4 (/ 2) workgroups: every wave keeps the chunks it swept before, the
+    partials travel as tagged granules to the unit's first workgroup, whose merge is unchanged -- tokens bit-equal to one workgroup per unit and to
+    the two-launch layer at every split factor and at the row counts next to the switches."""
+    clips = [synth.synth_waveform(120 + k, 0.9 + 0.21 * (k % 4)) for k in range(17)]
+    eng.set_tuning("chain", 0)
+    try:
+        for b in (1, 2, 4, 5, 8, 9, 16, 17):
+            eng.set_tuning("qa", 0)
+            want = eng.transcribe_batch(clips[:b], max_tokens=9, ignore_eos=True)
+            eng.set_tuning("qa", 1)
+            for split in (2, 1, 0):                            # 2: also two workgroups per unit at 9 .. 16 rows
+                eng.set_tuning("qa_split", split)
+                for _ in range(2):
+                    assert eng.transcribe_batch(clips[:b], max_tokens=9, ignore_eos=True) == want, (b, split)
+    finally:
+        eng.set_tuning("qa_split", 1)
+        eng.set_tuning("qa", 1)
