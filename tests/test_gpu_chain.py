@@ -190,3 +190,21 @@ def test_qa_context_split_at_small_batches(eng):
     finally:
         eng.set_tuning("qa_split", 1)
         eng.set_tuning("qa", 1)
+
+
+def test_hand_off_buffers_survive_changing_batch_sizes(eng):
+    """The granule and partial buffers are reused by every layer, step and batch; a tag is (step sequence word, layer), so what an earlier batch of
+    another size left behind -- rows the current batch does not write, partials of units that are not split now -- can never read as this launch's.
+    One engine, batches of 32 / 3 / 17 / 1 / 8 / 32 rows back to back, each with natural EOS, against the two-launch layer."""
+    clips = [synth.synth_waveform(200 + k, 0.7 + 0.19 * (k % 6)) for k in range(32)]
+    sizes = (32, 3, 17, 1, 8, 32, 5, 16)
+    eng.set_tuning("chain", 0)
+    try:
+        eng.set_tuning("qa", 0)
+        want = [eng.transcribe_batch(clips[:b], max_tokens=12) for b in sizes]
+        eng.set_tuning("qa", 1)
+        for _ in range(2):
+            got = [eng.transcribe_batch(clips[:b], max_tokens=12) for b in sizes]
+            assert got == want
+    finally:
+        eng.set_tuning("qa", 1)
