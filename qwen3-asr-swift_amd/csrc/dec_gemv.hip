@@ -179,6 +179,17 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     };
     // ---- 1. activation loads, then (once they are back, see mask_x) ALL weight fragments ------------------
     issue_x(0);
+    // norm weights: requested with the rows (2 KB every workgroup shares: cache hits).  Left inside the staging loop they were a dependent round
+    // trip behind the rows' wait, and hipcc sank the weight requests below them AND below the norm reduction (ISA of the gate|up instantiation:
+    // weights issued ~1 us after the rows were back)
+    // Only in the small-batch instantiations (EARLYW): at 32 rows the late order is the faster one (in-box A/B of two builds: decode 123.35 against
+    // 124.3 ms; +0.3 % / +0.7 % the other way at 1 / 8 rows) -- the same finding as for the weight stream itself, see the comment below.
+    constexpr bool HOISTNW = PRO == DEC_PRO_RMSNORM && EARLYW;
+    uint4 nwr[HOISTNW ? XI : 1];
+    if constexpr (HOISTNW) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
+    }
     if (!EARLYW) mask_x(0);
     uint4 w[NT][KSW];
 #pragma unroll
@@ -209,6 +220,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
         }
     }
     if (EARLYW) mask_x(0);
+    // the requests above stay above: the norm arithmetic below (a reduction with five dependent cross-lane steps) must not be scheduled in front of them
+    if constexpr (HOISTNW) __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[NT][NB];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -243,7 +256,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
             const float inv = rsqrtf(ss / (float)K + a2.eps);
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
-                const uint4 nw = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
+                uint4 nw;
+                if constexpr (HOISTNW) nw = nwr[i];
+                else nw = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
                 const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
                 const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
                 uint4 o;

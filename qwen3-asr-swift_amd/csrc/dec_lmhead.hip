@@ -60,10 +60,25 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
             }
         }
     };
-    if (nitems > 0) issue(wa, 0);
     // ---- stage + RMSNorm the batch rows, 16 rows per pass (row on 32 adjacent lanes) --------------------
+    // Request order: norm weights and the first pass's rows, THEN the first weight tiles -- loads come back in order, so rows asked for behind the
+    // weight prefetch could not be normalised before 16 KB of weights per wave had arrived from HBM; and the norm weights as whole 16-byte loads up
+    // front (inside the loop hipcc split each into four narrow loads, two of them behind a full wait).
     {
         const int srow = tid / TPR, scol = tid % TPR;
+        constexpr int NPRE = NB <= 2 ? NB : 1;          // passes whose rows are requested in front of the weights (registers: 4 per chunk)
+        uint4 nwr[XI], xr0[NPRE][XI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
+#pragma unroll
+        for (int nb = 0; nb < NPRE; ++nb) {
+            const bf16_t* xp0 = a.X + (long)(nb * 16 + srow < a.B ? nb * 16 + srow : 0) * K + scol * 8;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xr0[nb][i] = *reinterpret_cast<const uint4*>(xp0 + i * TPR * 8);
+        }
+        issue(wa, 0);       // unconditional (lm_head_supported: at least one tile per wave of the largest grid): under a branch hipcc's counted waits
+                            // for the rows would have to assume the shorter path and wait for the weights as well
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int r = nb * 16 + srow;
@@ -71,7 +86,10 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
             const bf16_t* xp = a.X + (long)(live ? r : 0) * K + scol * 8;
             uint4 xr[XI];
 #pragma unroll
-            for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+            for (int i = 0; i < XI; ++i) {
+                if (nb < NPRE) xr[i] = xr0[nb < NPRE ? nb : 0][i];
+                else xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+            }
             float ss = 0.0f;
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
@@ -88,7 +106,7 @@ __global__ __launch_bounds__(LMH_WAVES * 64) void lm_head_kernel(LmHeadArgs a) {
             char* xrow = s_x + (size_t)r * XSTRIDE + scol * 16;
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
-                const uint4 nw = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
+                const uint4 nw = nwr[i];
                 const bf16_t* e = reinterpret_cast<const bf16_t*>(&xr[i]);
                 const bf16_t* we = reinterpret_cast<const bf16_t*>(&nw);
                 uint4 o;
