@@ -126,7 +126,9 @@ struct DecGemv2Args {
 // NTW: weight fragments by non-temporal loads (a template parameter: as a run-time branch hipcc merged the two load blocks and dropped the
 // hint, round 2); A/B in profiles/r04_ab_gemv_nt.txt
 typedef __attribute__((ext_vector_type(4))) unsigned gemv_u32x4;
-template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false, bool EARLYW = false, bool NTW = false>
+// XBAR: the weight requests follow the row requests WITHOUT waiting for the rows to come back -- a bare s_barrier between the two makes every wave's row
+// requests enter the CU's request queue before any wave's weight requests, which is what the wait for the data was used for (see mask_x below).
+template <int NT, int NB, int WAVES, int KSW, bool ALLROWS, int PRO, int EPI, bool PARTIAL = false, bool EARLYW = false, bool NTW = false, bool XBAR = false>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     DecGemvArgs a = a2.g;
@@ -184,13 +186,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
     // weights issued ~1 us after the rows were back)
     // Only in the small-batch instantiations (EARLYW): at 32 rows the late order is the faster one (in-box A/B of two builds: decode 123.35 against
     // 124.3 ms; +0.3 % / +0.7 % the other way at 1 / 8 rows) -- the same finding as for the weight stream itself, see the comment below.
-    constexpr bool HOISTNW = PRO == DEC_PRO_RMSNORM && EARLYW;
+    constexpr bool HOISTNW = PRO == DEC_PRO_RMSNORM && (EARLYW || XBAR);
     uint4 nwr[HOISTNW ? XI : 1];
     if constexpr (HOISTNW) {
 #pragma unroll
         for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a2.norm_w)[scol + i * TPR];
     }
-    if (!EARLYW) mask_x(0);
+    if constexpr (XBAR) __builtin_amdgcn_s_barrier();
+    if (!EARLYW && !XBAR) mask_x(0);
     uint4 w[NT][KSW];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemv2_kernel(DecGemv2Args a
                 }
         }
     }
-    if (EARLYW) mask_x(0);
+    if (EARLYW || XBAR) mask_x(0);
     // the requests above stay above: the norm arithmetic below (a reduction with five dependent cross-lane steps) must not be scheduled in front of them
     if constexpr (HOISTNW) __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[NT][NB];
@@ -394,6 +397,15 @@ static bool gemv2_go(const DecGemv2Args& a2, hipStream_t s) {
         // non-temporal weight loads: only the plain full-tile instantiations carry the variant (EPI LOGITS is the generic head, untouched)
         if constexpr (!PARTIAL && EPI != DEC_EPI_LOGITS) {
             if (tuning().gemv_nt) { go(decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL, EARLYW, true>); return true; }
+        }
+        if constexpr (!PARTIAL && !EARLYW && EPI != DEC_EPI_LOGITS && NB == 1 && ALLROWS) {
+            // gemv_xbar: 1 residual GEMVs | 2 the norm GEMVs | 3 both | 4 (default) by batch: both up to 16 rows (-1.7 % decode at 16), the residual ones
+            // above (-0.2 % at 32; the norm GEMV, 384 workgroups there, loses 1.1 %) | 0 none
+            const int xb = tuning().gemv_xbar == 4 ? (a2.g.B <= 16 ? 3 : 1) : tuning().gemv_xbar;
+            if ((xb & 1 && EPI == DEC_EPI_RESID) || (xb & 2 && EPI != DEC_EPI_RESID)) {
+                go(decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL, EARLYW, false, true>);
+                return true;
+            }
         }
         go(decode_gemv2_kernel<NT, NB, WAVES, KSW, ALLROWS, PRO, EPI, PARTIAL, EARLYW, false>);
         return true;

@@ -13,7 +13,7 @@ namespace {
 // a value outside the table never reaches a kernel launch (decode_gran = 0 would divide by zero, lmh_grid <= 0 sizes empty buffers).
 struct Entry { const char* key; int Tuning::*field; int allowed[6]; bool diag_only; };
 const Entry kEntries[] = {
-    {"gemv_splitb", &Tuning::gemv_splitb, {0, 1, 2, -1}, false}, {"gemv_w1024", &Tuning::gemv_w1024, {4, 8, -1}, false},
+    {"gemv_splitb", &Tuning::gemv_splitb, {0, 1, 2, -1}, false}, {"gemv_xbar", &Tuning::gemv_xbar, {0, 1, 2, 3, 4, -1}, false}, {"gemv_w1024", &Tuning::gemv_w1024, {4, 8, -1}, false},
     {"gemv_nt", &Tuning::gemv_nt, {0, 1, -1}, false}, {"lmh_nt", &Tuning::lmh_nt, {0, 1, -1}, false},
     {"gemv_wide", &Tuning::gemv_wide, {0, 1, -1}, false}, {"gemv_earlyw", &Tuning::gemv_earlyw, {0, 1, 2, 3, -1}, false}, {"gemv_partial", &Tuning::gemv_partial, {0, 1, -1}, false},
     {"chain", &Tuning::chain, {0, 1, 2, 3, -1}, false}, {"chain_fault", &Tuning::chain_fault, {0, 1, -1}, false}, {"chain_proto", &Tuning::chain_proto, {0, 1, -1}, false}, {"chain_pf", &Tuning::chain_pf, {0, 1, -1}, false}, {"qa", &Tuning::qa, {0, 1, -1}, false},

@@ -9,6 +9,7 @@
 namespace qasr {
 
 struct Tuning {
+    int gemv_xbar = 4;       // decode GEMVs (16-row forms without the early weight stream): weight requests behind a bare barrier instead of behind the rows' return: 0 | 1 residual | 2 norm | 3 all | 4 by batch
     int gemv_splitb = 2;     // decode GEMV batch row groups on gridDim.y: 0 none | 1 residual GEMVs | 2 all
     int gemv_w1024 = 8;      // waves per workgroup for K = 1024 (8 x 4 k-steps | 4 x 8)
     int gemv_partial = 1;    // fewer than 16 batch rows: norm GEMVs skip the normalisation of rows past the end (own instantiation) | 0 off
