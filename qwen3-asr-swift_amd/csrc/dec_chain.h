@@ -67,6 +67,7 @@ struct DecQaArgs {
     // up to 16 batch rows: an attention unit spread over 2 / 4 / 8 workgroups (knob qa_split); their per-wave partials travel here,
     // [unit][8 waves][QA_PART_STRIDE] granules, same tags
     unsigned long long* part = nullptr;
+    int xbar = 0;
     const uint32_t* wq_qp = nullptr;
     const void* wq_sb = nullptr;
     int wq_bits = 0;

@@ -194,7 +194,12 @@ __global__ __launch_bounds__(CT, 2) void decode_qa_kernel(DecQaArgs a) {
             }
         }
     };
-    if constexpr (EARLY != 4) request_w();
+    if constexpr (EARLY != 4) {
+        // every wave's row requests enter the CU's request queue before any wave's weight requests (a bare barrier: nothing is waited for) -- the rows of
+        // a late wave otherwise queue behind the weight misses of the early ones: -0.7 % decode at 32 rows, nothing at 16 (knob qa_xbar)
+        if (a.xbar) __builtin_amdgcn_s_barrier();
+        request_w();
+    }
 
     const bf16_t* kb = cache.k + cache.off(bq, kvh, 0) + g * 8;
     const bf16_t* vfb = cache.vf + cache.off(bq, kvh, 0) + lane * 8;
@@ -609,6 +614,7 @@ bool decode_qa_supported(int H, int heads, int kv_heads, int hd, int B, int max_
 void decode_qa_launch(const DecQaArgs& a0, hipStream_t s) {
     DecQaArgs a = a0;
     a.fault = tuning().chain_fault;
+    a.xbar = tuning().qa_xbar == 2 ? (a.B > 16 ? 1 : 0) : tuning().qa_xbar;
     if (a.B < 1 || a.B > 32) throw std::invalid_argument("decode qa: 1..32 batch rows");
     if (!a.cache.vf || a.cache.max_ctx % 32) throw std::invalid_argument("decode qa: fragment-major V image / capacity");
     auto go = [&](auto k) {

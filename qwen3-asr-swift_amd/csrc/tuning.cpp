@@ -17,7 +17,7 @@ const Entry kEntries[] = {
     {"gemv_nt", &Tuning::gemv_nt, {0, 1, -1}, false}, {"lmh_nt", &Tuning::lmh_nt, {0, 1, -1}, false},
     {"gemv_wide", &Tuning::gemv_wide, {0, 1, -1}, false}, {"gemv_earlyw", &Tuning::gemv_earlyw, {0, 1, 2, 3, -1}, false}, {"gemv_partial", &Tuning::gemv_partial, {0, 1, -1}, false},
     {"chain", &Tuning::chain, {0, 1, 2, 3, -1}, false}, {"chain_fault", &Tuning::chain_fault, {0, 1, -1}, false}, {"chain_proto", &Tuning::chain_proto, {0, 1, -1}, false}, {"chain_pf", &Tuning::chain_pf, {0, 1, -1}, false}, {"qa", &Tuning::qa, {0, 1, -1}, false},
-    {"qa_early", &Tuning::qa_early, {0, 5, -2}, false}, {"qa_gate", &Tuning::qa_gate, {0, 1, 2, -1}, false}, {"qa_gran", &Tuning::qa_gran, {0, 1, -1}, false}, {"qa_split", &Tuning::qa_split, {0, 1, 2, -1}, false},
+    {"qa_early", &Tuning::qa_early, {0, 5, -2}, false}, {"qa_gate", &Tuning::qa_gate, {0, 1, 2, -1}, false}, {"qa_gran", &Tuning::qa_gran, {0, 1, -1}, false}, {"qa_split", &Tuning::qa_split, {0, 1, 2, -1}, false}, {"qa_xbar", &Tuning::qa_xbar, {0, 1, 2, -1}, false},
     {"da_unr", &Tuning::da_unr, {1, 2, -1}, false},
     {"da_waves", &Tuning::da_waves, {8, 16, -1}, false}, {"da_spec", &Tuning::da_spec, {0, 1, 2, 3, -1}, false}, {"da_earlyq", &Tuning::da_earlyq, {0, 1, -1}, false},
     {"pa_form", &Tuning::pa_form, {1, 2, -1}, false}, {"pa_mt", &Tuning::pa_mt, {1, 2, -1}, false}, {"pa_order", &Tuning::pa_order, {0, 1, -1}, false}, {"pa_vfrag", &Tuning::pa_vfrag, {0, 1, -1}, false},

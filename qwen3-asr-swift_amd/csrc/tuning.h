@@ -23,6 +23,7 @@ struct Tuning {
     int qa_early = 5;        // dec_qa: when the K half of each wave's first chunk is requested: 0 with the rest (after the projection's sums) | 1 behind the
                              // weight tile | 2 like 1 on waves 4..7 only | 3 once the wave's activation rows are staged | 4 in front of the weight tile |
                              // 5 (default) 3 above 16 batch rows, 4 up to 16
+    int qa_xbar = 2;         // dec_qa: a bare barrier between the row requests and the weight requests: 0 | 1 | 2 = above 16 rows
     int qa_split = 1;        // dec_qa: 1 up to 8 batch rows an attention unit's context goes over 8 / 4 workgroups (partials handed over as granules) | 2 also 9..16 rows over 2 | 0 one workgroup per unit
     int qa_gran = 1;         // dec_qa hand-off: 1 data-tagged 8-byte granules (the data is the flag) | 0 write-through rows + arrival counter + sc1 row loads
     int qa_gate = 2;         // dec_qa: 1 waves 1..7 hold their remaining K / V requests until wave 0 has sent the projection off | 0 as soon as the sums are in | 2 = 1 with granules, 0 with the counter form
