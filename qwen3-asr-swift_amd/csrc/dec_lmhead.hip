@@ -290,19 +290,31 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
         for (int i = tid; i < st.clear_words; i += 256) st.clear[i] = 0u;
         if (tid == 0 && st.clear_words) st.clear[st.clear_words + 32] += 1u;      // the step sequence word (dec_chain.h CHAIN_SEQ_WORD)
     }
-    // position of the NEXT decode step for this row; its rope row is copied next to the batch row so that
-    // the attention kernels of that step need not chain a table lookup behind the ctx_len load
-    const int next_pos = st.ctx_len[b] + (advance_ctx ? 1 : 0);
-    if (tid < rr.half) {
-        rr.cos_rows[(long)b * rr.half + tid] = rr.cos_table[(long)next_pos * rr.half + tid];
-        rr.sin_rows[(long)b * rr.half + tid] = rr.sin_table[(long)next_pos * rr.half + tid];
-    }
+    // Request order (the launch was a chain of ~9 dependent round trips, one per step of the bookkeeping): everything that depends on nothing --
+    // the row's state words, the argmax partials -- is requested up front; the rope row of the NEXT step's position (copied next to the batch row
+    // so that the attention of that step need not chain a table lookup behind the ctx_len load) is one round trip behind ctx_len, both tables together.
+    const int ctx_now = st.ctx_len[b];
+    const int fin_now = st.finished[b], len_now = st.lens[b];
     float best = -INFINITY;
     int bidx = 0x7fffffff;
-    for (int i = tid; i < n_parts; i += 256) {
-        const float v = part_val[(long)b * n_parts + i];
-        const int n = part_idx[(long)b * n_parts + i];
-        if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+    if (n_parts <= 256) {                              // one partial per thread: a plain load each, in flight with the words above
+        if (tid < n_parts) {
+            const float v = part_val[(long)b * n_parts + tid];
+            const int n = part_idx[(long)b * n_parts + tid];
+            if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+        }
+    } else {
+        for (int i = tid; i < n_parts; i += 256) {
+            const float v = part_val[(long)b * n_parts + i];
+            const int n = part_idx[(long)b * n_parts + i];
+            if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+        }
+    }
+    const int next_pos = ctx_now + (advance_ctx ? 1 : 0);
+    if (tid < rr.half) {
+        const float c = rr.cos_table[(long)next_pos * rr.half + tid], sn = rr.sin_table[(long)next_pos * rr.half + tid];
+        rr.cos_rows[(long)b * rr.half + tid] = c;
+        rr.sin_rows[(long)b * rr.half + tid] = sn;
     }
     s_v[tid] = best;
     s_i[tid] = bidx;
@@ -318,10 +330,10 @@ __global__ __launch_bounds__(256) void greedy_finalize_kernel(const float* __res
     const bool sane = (unsigned)s_i[0] < (unsigned)st.vocab && fabsf(s_v[0]) <= 3.0e38f;   // false for NaN / inf / no winner
     const int tok = (unsigned)s_i[0] < (unsigned)st.vocab ? s_i[0] : 0;
     if (tid == 0) {
-        if (!sane && !st.finished[b]) atomicOr(st.err, 1);
-        if (advance_ctx) st.ctx_len[b] += 1;
-        if (!st.finished[b]) {
-            const int n = st.lens[b];
+        if (!sane && !fin_now) atomicOr(st.err, 1);
+        if (advance_ctx) st.ctx_len[b] = ctx_now + 1;
+        if (!fin_now) {
+            const int n = len_now;
             st.tokens[(long)b * (st.max_new + 1) + n] = tok;
             st.lens[b] = n + 1;
             if ((tok == st.eos && !st.ignore_eos) || n + 1 >= st.max_tokens) {
