@@ -5,8 +5,11 @@ import numpy as np
 from qasr import synth, config as QC
 from qasr.model import Qwen3ASRModel
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 sd = synth.synth_state_dict(QC.AUDIO_SMALL, QC.TEXT_SMALL, seed=0, init="hf")
-m = Qwen3ASRModel.from_state_dict(sd, preset="0.6B", max_batch=32, max_audio_seconds=30, max_new_tokens=448)
+if BITS != 16:
+    sd = synth.quantize_state_dict(sd, BITS)
+m = Qwen3ASRModel.from_state_dict(sd, preset="0.6B", max_batch=32, max_audio_seconds=30, max_new_tokens=448, **({"bits": BITS} if BITS != 16 else {}))
 clips = [synth.synth_waveform(k, 30.0 - 0.5 * (k % 7)) for k in range(32)]
 sizes = [32, 1, 8, 32, 3, 16, 32, 5, 17, 32]
 ref = {}
@@ -19,5 +22,5 @@ for it in range(N):
     h = hash(toks[:b].tobytes())
     if key not in ref: ref[key] = h
     assert ref[key] == h, (it, b)
-print(f"soak ok: {N} passes, sizes {sorted(ref)} in {time.time() - t0:.1f} s")
+print(f"soak ok ({BITS} bit): {N} passes, sizes {sorted(ref)} in {time.time() - t0:.1f} s")
 m.close()
