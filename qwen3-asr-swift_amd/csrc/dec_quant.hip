@@ -187,7 +187,8 @@ struct DecGemvQArgs {
 
 // KPH > 1 (K = 6144, the 1.7B preset's down-projection: 16 rows x 12 KiB do not fit the LDS): the activation rows pass through the
 // same LDS image in KPH column phases of K / KPH columns; all packed weights and all rows are requested up front as before.
-template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI, int KPH = 1>
+// XBAR: as in decode_gemv2_kernel -- the weight requests follow the row requests behind a bare s_barrier instead of behind the rows' return
+template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI, int KPH = 1, bool XBAR = false>
 __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a2) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int BLK = BITS == 4 ? 128 : 64, GPB = BLK / 64;
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
     {
 #pragma unroll
         for (int i = 0; i < XI; ++i) xr[0][i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
-        if (srow >= a.B) {
+        if constexpr (XBAR) __builtin_amdgcn_s_barrier();
+        else if (srow >= a.B) {
 #pragma unroll
             for (int i = 0; i < XI; ++i) xr[0][i] = make_uint4(0, 0, 0, 0);
         }
@@ -256,6 +258,12 @@ __global__ __launch_bounds__(WAVES * 64) void decode_gemvq_kernel(DecGemvQArgs a
     for (int kp = 1; kp < KPH; ++kp)
 #pragma unroll
         for (int i = 0; i < XI; ++i) xr[kp][i] = *reinterpret_cast<const uint4*>(xp + kp * KH + i * TPR * 8);
+    if constexpr (XBAR) {
+        if (srow >= a.B) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xr[0][i] = make_uint4(0, 0, 0, 0);
+        }
+    }
     // the requests above stay above: left to itself the scheduler sinks them below the RMSNorm reduction (five dependent
     // cross-lane steps), i.e. the weights are asked for a microsecond late
     __builtin_amdgcn_sched_barrier(0);
@@ -365,9 +373,21 @@ template <int BITS, bool SBF32, int NT, int WAVES, int KBW, int PRO, int EPI, in
 static bool gemvq_go(const DecGemvQArgs& a2, hipStream_t s) {
     constexpr size_t lds = gemvq_lds<BITS, WAVES, KBW, NT>();
     static_assert(lds <= 156 * 1024, "LDS image too large");
+    const dim3 grid(a2.g.N / (16 * NT), (a2.g.B + 15) / 16);
+    if constexpr (KPH == 1) {
+        // the rule of decode_gemv2_kernel (knob gemv_xbar): every GEMV up to 16 rows, the residual ones above; not below 8 rows (4-bit decode, xbar | wait:
+        // 122.49 | 122.69 ms at 32 clips, 101.04 | 101.95 at 8, 94.2 | 93.0 at 1: with a row or two there is nothing to order)
+        const int xb = tuning().gemv_xbar == 4 ? (a2.g.B < 8 ? 0 : a2.g.B <= 16 ? 3 : 1) : tuning().gemv_xbar;
+        if ((xb & 1 && EPI == DEC_EPI_RESID) || (xb & 2 && EPI != DEC_EPI_RESID)) {
+            auto kx = decode_gemvq_kernel<BITS, SBF32, NT, WAVES, KBW, PRO, EPI, KPH, true>;
+            ensure_dynamic_lds(reinterpret_cast<const void*>(kx), (int)lds);
+            hipLaunchKernelGGL(kx, grid, dim3(WAVES * 64), lds, s, a2);
+            return true;
+        }
+    }
     auto kern = decode_gemvq_kernel<BITS, SBF32, NT, WAVES, KBW, PRO, EPI, KPH>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
-    hipLaunchKernelGGL(kern, dim3(a2.g.N / (16 * NT), (a2.g.B + 15) / 16), dim3(WAVES * 64), lds, s, a2);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, a2);
     return true;
 }
 
