@@ -586,27 +586,45 @@ __global__ __launch_bounds__(LMQ_WAVES * 64) void lm_head_q_kernel(LmHeadQArgs a
         }
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + lane * 16), (lds_ptr_t)(ring + (seq % (LR > 0 ? LR : 1)) * 1024), 16, 0, 0);
     };
+    // Request order as in lm_head_kernel (dec_lmhead.hip): the norm weights and the first pass's rows go out IN FRONT of the weight prefetch, whose LR
+    // requests are unrolled so that the rows' counted wait stays exact -- behind the prefetch, the rows could not be normalised before the ring's first
+    // fill had landed (ISA: a full vmcnt(0) in front of the norm weights, then a second round trip for the rows).
+    const int srow = tid / TPR, scol = tid % TPR;
+    uint4 nwr[XI], xr0[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
+    {
+        const bf16_t* xp0 = a.X + (long)(srow < a.B ? srow : 0) * K + scol * 8;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xr0[i] = *reinterpret_cast<const uint4*>(xp0 + i * TPR * 8);
+    }
     if constexpr (LR > 0) {
-#pragma unroll 1
+        // hipcc waits with vmcnt(0) for anything that precedes direct-to-LDS copies still in flight, so the rows are waited for HERE, before the ring's
+        // first fill is requested (a cache round trip, ~1 us): their normalisation then runs under the fill instead of behind it
+        reg_use(xr0);
+        reg_use(nwr);
+#pragma unroll
         for (int r = 0; r < LR; ++r) issue(r);
     } else if (nblocks > 0) {
 #pragma unroll
         for (int r = 0; r < RING; ++r) load_blk(qr[r], scr[r], bir[r], r);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- stage + RMSNorm the batch rows, 16 rows per pass; group sums of the staged values ------------------
     {
-        const int srow = tid / TPR, scol = tid % TPR;
-        uint4 nwr[XI];
-#pragma unroll
-        for (int i = 0; i < XI; ++i) nwr[i] = reinterpret_cast<const uint4*>(a.norm_w)[scol + i * TPR];
 #pragma unroll 1
         for (int nb = 0; nb < NB; ++nb) {
             const int r = nb * 16 + srow;
             const bool live = r < a.B;
             const bf16_t* xp = a.X + (long)(live ? r : 0) * K + scol * 8;
             uint4 xr[XI];
+            if (nb == 0) {
 #pragma unroll
-            for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+                for (int i = 0; i < XI; ++i) xr[i] = xr0[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < XI; ++i) xr[i] = *reinterpret_cast<const uint4*>(xp + i * TPR * 8);
+            }
             float ss = 0.0f;
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
